@@ -1,0 +1,135 @@
+"""HRNet on MI355X: same import path, constructor, call signature and state_dict as the reference's
+`src/DeepNetworks/HRNet.py` (HRNet :172-211; Encoder :36-74; RecuversiveNet :77-134; Decoder :138-169;
+ResidualBlock :7-33), computed by the hand-written gfx950 kernels of libhrnet_hip.so.
+
+The nn.Module tree below only *holds parameters* under the reference's names (so checkpoints load and
+`torch.manual_seed` reproduces the reference's default initialisation: the same layer types are created in
+the same order).  None of the sub-modules is ever called: `HRNet.forward` hands the tensors to the C ABI
+(`hrn_hrnet_forward`), which runs median -> stem -> encoder -> recursive pairwise fusion -> decoder.
+
+Precision (`HRNet.precision`, or key "precision" in the config dict, or env HRNET_HIP_PRECISION):
+    "fp32" (default)  exact-fp32 MFMA; matches the reference forward to ~1e-6 relative
+    "bf16"            bf16 activations/weights, fp32 accumulation; the throughput path (BASELINE config 3)
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from hrnet_hip import binding
+
+_PRECISIONS = {"fp32": binding.F32, "f32": binding.F32, "float32": binding.F32, "bf16": binding.BF16, "bfloat16": binding.BF16}
+
+
+class _Holder(nn.Module):
+    """Parameter container: exists for state_dict()/parameters()/to(); never executed."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError(f"{type(self).__name__} holds parameters only; call HRNet(lrs, alphas)")
+
+
+class ResidualBlock(_Holder):
+    def __init__(self, channel_size=64, kernel_size=3):
+        super().__init__()
+        pad = kernel_size // 2
+        self.block = nn.Sequential(nn.Conv2d(channel_size, channel_size, kernel_size, padding=pad), nn.PReLU(),
+                                   nn.Conv2d(channel_size, channel_size, kernel_size, padding=pad), nn.PReLU())
+
+
+class Encoder(_Holder):
+    def __init__(self, config):
+        super().__init__()
+        cin, layers, k, c = config["in_channels"], config["num_layers"], config["kernel_size"], config["channel_size"]
+        self.init_layer = nn.Sequential(nn.Conv2d(cin, c, k, padding=k // 2), nn.PReLU())
+        self.res_layers = nn.Sequential(*[ResidualBlock(c, k) for _ in range(layers)])
+        self.final = nn.Sequential(nn.Conv2d(c, c, k, padding=k // 2))
+
+
+class RecuversiveNet(_Holder):
+    def __init__(self, config):
+        super().__init__()
+        self.input_channels = config["in_channels"]
+        self.num_layers = config["num_layers"]
+        self.alpha_residual = config["alpha_residual"]
+        k = config["kernel_size"]
+        c = self.input_channels
+        self.fuse = nn.Sequential(ResidualBlock(2 * c, k), nn.Conv2d(2 * c, c, k, padding=k // 2), nn.PReLU())
+
+
+class Decoder(_Holder):
+    def __init__(self, config):
+        super().__init__()
+        d, f = config["deconv"], config["final"]
+        self.deconv = nn.Sequential(nn.ConvTranspose2d(d["in_channels"], d["out_channels"], d["kernel_size"], stride=d["stride"]),
+                                    nn.PReLU())
+        self.final = nn.Conv2d(f["in_channels"], f["out_channels"], f["kernel_size"], padding=f["kernel_size"] // 2)
+
+
+def _check_config(config):
+    e, r, d = config["encoder"], config["recursive"], config["decoder"]
+    ok = (e["in_channels"] == 2 and e["kernel_size"] == 3 and e["channel_size"] == 64 and 0 <= e["num_layers"] <= binding.MAX_RES_LAYERS
+          and r["in_channels"] == 64 and r["kernel_size"] == 3
+          and d["deconv"]["in_channels"] == 64 and d["deconv"]["out_channels"] == 64 and d["deconv"]["kernel_size"] == 3
+          and d["deconv"]["stride"] == 3 and d["final"]["in_channels"] == 64 and d["final"]["out_channels"] == 1
+          and d["final"]["kernel_size"] == 1)
+    if not ok:
+        raise NotImplementedError(
+            "the gfx950 kernels are specialised for the reference's shipped network (config/config.json:8-34): "
+            "2->64 stem, 64-channel 3x3 convs, stride-3 k3 deconv, 1x1 final; got " + repr(config))
+
+
+class HRNet(nn.Module):
+    """HRNet(config["network"]); forward(lrs (B,L,H,W), alphas (B,L)) -> (B,1,3H,3W)."""
+
+    def __init__(self, config):
+        super().__init__()
+        _check_config(config)
+        self.encode = Encoder(config["encoder"])
+        self.fuse = RecuversiveNet(config["recursive"])
+        self.decode = Decoder(config["decoder"])
+        self._num_layers = config["encoder"]["num_layers"]
+        self.precision = config.get("precision", os.environ.get("HRNET_HIP_PRECISION", "fp32"))
+        self._packed = None
+        self._packed_key = None
+
+    # -- packed-parameter cache: re-packed whenever a parameter was modified (optimizer step, load_state_dict, .to())
+    def _dtype(self):
+        try:
+            return _PRECISIONS[str(self.precision).lower()]
+        except KeyError:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}; got {self.precision!r}")
+
+    def packed_parameters(self):
+        dt = self._dtype()
+        named = dict(self.named_parameters())
+        key = (dt,) + tuple((p.data_ptr(), p._version) for p in named.values())
+        if self._packed is None or self._packed_key != key:
+            self._packed = binding.hrnet_pack(named, self._num_layers, dt)
+            self._packed_key = key
+        return self._packed, dt
+
+    def forward(self, lrs, alphas):
+        if lrs.dim() != 4:
+            raise ValueError(f"lrs must be (B, L, H, W); got {tuple(lrs.shape)}")
+        if lrs.shape[2] != lrs.shape[3]:
+            raise ValueError("square low-res images only: the reference reinterprets (H,W) as (W,H) in its .view() "
+                             "(HRNet.py:204), which is the identity only for H == W")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError(
+                "backward kernels are not built yet (SURVEY.md section 8 row f3): run the HIP HRNet under torch.no_grad() "
+                "or in eval() mode")
+        packed, dt = self.packed_parameters()
+        return binding.hrnet_forward(packed, dt, self._num_layers, self.fuse.alpha_residual, lrs.detach(), alphas.detach())
+
+    # -- staged access for parity tests / profiling (channels-last tensors in the storage dtype)
+    def encode_views(self, lrs):
+        packed, dt = self.packed_parameters()
+        return binding.hrnet_encoder(packed, dt, self._num_layers, lrs)
+
+    def fuse_views(self, emb, alphas):
+        packed, dt = self.packed_parameters()
+        return binding.hrnet_fuse(packed, dt, self._num_layers, self.fuse.alpha_residual, emb, alphas)
+
+    def decode_state(self, fused):
+        packed, dt = self.packed_parameters()
+        return binding.hrnet_decoder(packed, dt, self._num_layers, fused)

@@ -1,0 +1,315 @@
+"""ctypes binding of libhrnet_hip.so (C ABI: include/hrnet_hip.h) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory (`tensor.data_ptr()`), the current HIP stream and, for
+multi-GPU, `torch.distributed`.  All arithmetic happens in the hand-written gfx950 kernels of the library.
+There is NO fallback: if the library is missing or a tensor is not on a ROCm device, these functions raise.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhrnet_hip.so")
+
+F32, BF16 = 0, 1
+MAX_RES_LAYERS = 8
+_DT_TORCH = {F32: torch.float32, BF16: torch.bfloat16}
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+class HrnetParams(ctypes.Structure):
+    _fields_ = [
+        ("num_layers", ctypes.c_int),
+        ("enc_init_w", ctypes.c_void_p), ("enc_init_b", ctypes.c_void_p), ("enc_init_a", ctypes.c_void_p),
+        ("enc_res_w", ctypes.c_void_p * (2 * MAX_RES_LAYERS)),
+        ("enc_res_b", ctypes.c_void_p * (2 * MAX_RES_LAYERS)),
+        ("enc_res_a", ctypes.c_void_p * (2 * MAX_RES_LAYERS)),
+        ("enc_final_w", ctypes.c_void_p), ("enc_final_b", ctypes.c_void_p),
+        ("fuse_res_w", ctypes.c_void_p * 2), ("fuse_res_b", ctypes.c_void_p * 2), ("fuse_res_a", ctypes.c_void_p * 2),
+        ("fuse_out_w", ctypes.c_void_p), ("fuse_out_b", ctypes.c_void_p), ("fuse_out_a", ctypes.c_void_p),
+        ("dec_w", ctypes.c_void_p), ("dec_b", ctypes.c_void_p), ("dec_a", ctypes.c_void_p),
+        ("fin_w", ctypes.c_void_p), ("fin_b", ctypes.c_void_p),
+    ]
+
+
+class ShiftnetParams(ctypes.Structure):
+    _fields_ = [
+        ("conv_w", ctypes.c_void_p * 8), ("conv_b", ctypes.c_void_p * 8),
+        ("bn_g", ctypes.c_void_p * 8), ("bn_b", ctypes.c_void_p * 8),
+        ("bn_rm", ctypes.c_void_p * 8), ("bn_rv", ctypes.c_void_p * 8),
+        ("fc1_w", ctypes.c_void_p), ("fc1_b", ctypes.c_void_p), ("fc2_w", ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/hrnet_hip.h declares (checked by tests/test_abi.py)
+_c = ctypes
+SIGNATURES = {
+    "hrn_version": (_c.c_int, []),
+    "hrn_last_error": (_c.c_char_p, []),
+    "hrn_hrnet_packed_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "hrn_hrnet_pack": (_c.c_int, [_c.POINTER(HrnetParams), _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_hrnet_workspace_bytes": (_c.c_size_t, [_c.c_int] * 5),
+    "hrn_hrnet_forward": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                     _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_encoder_forward": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                       _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_fuse_forward": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
+                                    _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_decoder_forward": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                       _c.c_void_p, _c.c_void_p]),
+    "hrn_shiftnet_packed_bytes": (_c.c_size_t, []),
+    "hrn_shiftnet_pack": (_c.c_int, [_c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_shiftnet_workspace_bytes": (_c.c_size_t, [_c.c_int]),
+    "hrn_shiftnet_forward": (_c.c_int, [_c.c_void_p, _c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_int, _c.c_int, _c.c_float,
+                                        _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_lanczos_kernel": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "hrn_lanczos_shift": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen the in-tree library and type every entry point.  Raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python highres-net_amd/hrnet_hip/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback for the HIP path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError here == ABI mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class HrnetHipError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().hrn_last_error().decode("utf-8", "replace")
+        raise HrnetHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def _dev_f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on '{t.device}': the HIP path needs ROCm device tensors (no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# --------------------------------------------------------------------------- HRNet
+def hrnet_pack(named, num_layers, dtype):
+    """named: dict of reference state-dict keys -> device f32 tensors.  Returns the packed uint8 tensor."""
+    lib = load_library()
+    keep = []
+
+    def p(key):
+        t = _dev_f32(named[key].detach(), key)
+        keep.append(t)
+        return t.data_ptr()
+
+    P = HrnetParams()
+    P.num_layers = num_layers
+    P.enc_init_w, P.enc_init_b, P.enc_init_a = p("encode.init_layer.0.weight"), p("encode.init_layer.0.bias"), p("encode.init_layer.1.weight")
+    for l in range(num_layers):
+        for j, (cw, ca) in enumerate(((0, 1), (2, 3))):
+            P.enc_res_w[2 * l + j] = p(f"encode.res_layers.{l}.block.{cw}.weight")
+            P.enc_res_b[2 * l + j] = p(f"encode.res_layers.{l}.block.{cw}.bias")
+            P.enc_res_a[2 * l + j] = p(f"encode.res_layers.{l}.block.{ca}.weight")
+    P.enc_final_w, P.enc_final_b = p("encode.final.0.weight"), p("encode.final.0.bias")
+    for j, (cw, ca) in enumerate(((0, 1), (2, 3))):
+        P.fuse_res_w[j] = p(f"fuse.fuse.0.block.{cw}.weight")
+        P.fuse_res_b[j] = p(f"fuse.fuse.0.block.{cw}.bias")
+        P.fuse_res_a[j] = p(f"fuse.fuse.0.block.{ca}.weight")
+    P.fuse_out_w, P.fuse_out_b, P.fuse_out_a = p("fuse.fuse.1.weight"), p("fuse.fuse.1.bias"), p("fuse.fuse.2.weight")
+    P.dec_w, P.dec_b, P.dec_a = p("decode.deconv.0.weight"), p("decode.deconv.0.bias"), p("decode.deconv.1.weight")
+    P.fin_w, P.fin_b = p("decode.final.weight"), p("decode.final.bias")
+    nbytes = lib.hrn_hrnet_packed_bytes(dtype, num_layers)
+    if nbytes == 0:
+        raise HrnetHipError(f"unsupported dtype/num_layers ({dtype}, {num_layers})")
+    dev = keep[0].device
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.hrn_hrnet_pack(ctypes.byref(P), dtype, _ptr(packed), nbytes, _stream()), "hrn_hrnet_pack")
+    return packed
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    key = (tag, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _ws_cache.pop(key, None)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def hrnet_workspace(dtype, B, V, H, W, device):
+    n = load_library().hrn_hrnet_workspace_bytes(dtype, B, V, H, W)
+    if n == 0:
+        raise HrnetHipError(f"bad HRNet problem size B={B} V={V} H={H} W={W}")
+    return _workspace(n, device, "hrnet")
+
+
+def hrnet_forward(packed, dtype, num_layers, alpha_residual, lrs, alphas, out=None):
+    lib = load_library()
+    lrs = _dev_f32(lrs, "lrs")
+    alphas = _dev_f32(alphas, "alphas").to(lrs.device)
+    if lrs.dim() != 4 or alphas.shape != lrs.shape[:2]:
+        raise ValueError(f"lrs must be (B,V,H,W) and alphas (B,V); got {tuple(lrs.shape)} / {tuple(alphas.shape)}")
+    B, V, H, W = lrs.shape
+    with torch.cuda.device(lrs.device):
+        ws = hrnet_workspace(dtype, B, V, H, W, lrs.device)
+        sr = out if out is not None else torch.empty((B, 1, 3 * H, 3 * W), dtype=torch.float32, device=lrs.device)
+        _check(lib.hrn_hrnet_forward(_ptr(packed), dtype, num_layers, int(bool(alpha_residual)), _ptr(lrs), _ptr(alphas),
+                                     B, V, H, W, _ptr(sr), _ptr(ws), ws.numel(), _stream()), "hrn_hrnet_forward")
+    return sr
+
+
+def hrnet_encoder(packed, dtype, num_layers, lrs):
+    """-> view stack (B,V,H,W,64) channels-last in the storage dtype."""
+    lib = load_library()
+    lrs = _dev_f32(lrs, "lrs")
+    B, V, H, W = lrs.shape
+    with torch.cuda.device(lrs.device):
+        ws = hrnet_workspace(dtype, B, V, H, W, lrs.device)
+        emb = torch.empty((B, V, H, W, 64), dtype=_DT_TORCH[dtype], device=lrs.device)
+        _check(lib.hrn_encoder_forward(_ptr(packed), dtype, num_layers, _ptr(lrs), B, V, H, W, _ptr(emb), _ptr(ws), ws.numel(),
+                                       _stream()), "hrn_encoder_forward")
+    return emb
+
+
+def hrnet_fuse(packed, dtype, num_layers, alpha_residual, emb, alphas):
+    """emb (B,V,H,W,64) storage dtype (destroyed) -> fused (B,H,W,64)."""
+    lib = load_library()
+    if emb.dtype != _DT_TORCH[dtype] or not emb.is_contiguous() or not emb.is_cuda:
+        raise ValueError("emb must be a contiguous device tensor in the storage dtype")
+    B, V, H, W, _ = emb.shape
+    alphas = _dev_f32(alphas, "alphas")
+    with torch.cuda.device(emb.device):
+        ws = hrnet_workspace(dtype, B, V, H, W, emb.device)
+        fused = torch.empty((B, H, W, 64), dtype=emb.dtype, device=emb.device)
+        _check(lib.hrn_fuse_forward(_ptr(packed), dtype, num_layers, int(bool(alpha_residual)), _ptr(emb), _ptr(alphas),
+                                    B, V, H, W, _ptr(fused), _ptr(ws), ws.numel(), _stream()), "hrn_fuse_forward")
+    return fused
+
+
+def hrnet_decoder(packed, dtype, num_layers, fused):
+    lib = load_library()
+    if fused.dtype != _DT_TORCH[dtype] or not fused.is_contiguous() or not fused.is_cuda:
+        raise ValueError("fused must be a contiguous device tensor in the storage dtype")
+    N, H, W, _ = fused.shape
+    with torch.cuda.device(fused.device):
+        sr = torch.empty((N, 1, 3 * H, 3 * W), dtype=torch.float32, device=fused.device)
+        _check(lib.hrn_decoder_forward(_ptr(packed), dtype, num_layers, _ptr(fused), N, H, W, _ptr(sr), _stream()), "hrn_decoder_forward")
+    return sr
+
+
+# --------------------------------------------------------------------------- ShiftNet
+def _shiftnet_struct(named, keep, with_weights):
+    P = ShiftnetParams()
+
+    def p(key):
+        t = named[key].detach()
+        if not t.is_cuda:
+            raise RuntimeError(f"{key} is on '{t.device}': ShiftNet parameters must live on the ROCm device")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"{key} must be contiguous float32")
+        keep.append(t)
+        return t.data_ptr()
+
+    for i in range(8):
+        if with_weights:
+            P.conv_w[i], P.conv_b[i] = p(f"layer{i + 1}.0.weight"), p(f"layer{i + 1}.0.bias")
+        P.bn_g[i], P.bn_b[i] = p(f"layer{i + 1}.1.weight"), p(f"layer{i + 1}.1.bias")
+        P.bn_rm[i], P.bn_rv[i] = p(f"layer{i + 1}.1.running_mean"), p(f"layer{i + 1}.1.running_var")
+    if with_weights:
+        P.fc1_w, P.fc1_b, P.fc2_w = p("fc1.weight"), p("fc1.bias"), p("fc2.weight")
+    return P
+
+
+def shiftnet_pack(named):
+    lib = load_library()
+    keep = []
+    P = _shiftnet_struct(named, keep, True)
+    dev = keep[0].device
+    nbytes = lib.hrn_shiftnet_packed_bytes()
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.hrn_shiftnet_pack(ctypes.byref(P), _ptr(packed), nbytes, _stream()), "hrn_shiftnet_pack")
+    return packed
+
+
+def shiftnet_forward(packed, named, x, train_bn=False, momentum=0.1, dropout_mask=None):
+    """x (B,2,128,128) -> theta (B,2).  `named` supplies the live BatchNorm tensors (running stats are updated in
+    place when train_bn).  dropout_mask: None or uint8 (B,32768) keep-mask in the reference's flatten order."""
+    lib = load_library()
+    x = _dev_f32(x, "x")
+    if x.dim() != 4 or tuple(x.shape[1:]) != (2, 128, 128):
+        raise ValueError(f"ShiftNet input must be (B,2,128,128) (fc1 is hard-wired to 128*16*16, ShiftNet.py:44); got {tuple(x.shape)}")
+    B = x.shape[0]
+    keep = []
+    P = _shiftnet_struct(named, keep, False)
+    mptr = ctypes.c_void_p(0)
+    if dropout_mask is not None:
+        if dropout_mask.dtype != torch.uint8 or tuple(dropout_mask.shape) != (B, 32768) or not dropout_mask.is_cuda:
+            raise ValueError("dropout_mask must be a uint8 device tensor of shape (B, 32768)")
+        dropout_mask = dropout_mask.contiguous()
+        mptr = _ptr(dropout_mask)
+    with torch.cuda.device(x.device):
+        nws = lib.hrn_shiftnet_workspace_bytes(B)
+        ws = _workspace(nws, x.device, "shiftnet")
+        theta = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+        _check(lib.hrn_shiftnet_forward(_ptr(packed), ctypes.byref(P), _ptr(x), B, int(bool(train_bn)), float(momentum), mptr,
+                                        _ptr(theta), _ptr(ws), ws.numel(), _stream()), "hrn_shiftnet_forward")
+    return theta
+
+
+# --------------------------------------------------------------------------- Lanczos
+def lanczos_kernel(dx):
+    lib = load_library()
+    dx = _dev_f32(dx, "dx").reshape(-1)
+    n = dx.numel()
+    taps = torch.empty((n, 7), dtype=torch.float32, device=dx.device)
+    with torch.cuda.device(dx.device):
+        _check(lib.hrn_lanczos_kernel(_ptr(dx), n, _ptr(taps), _stream()), "hrn_lanczos_kernel")
+    return taps
+
+
+def lanczos_shift(img, shift):
+    lib = load_library()
+    img = _dev_f32(img, "img")
+    shift = _dev_f32(shift, "shift").to(img.device)
+    if img.dim() != 4 or shift.dim() != 2 or shift.shape[1] != 2 or shift.shape[0] < img.shape[1]:
+        raise ValueError(f"img must be (b,c,H,W) and shift (c,2); got {tuple(img.shape)} / {tuple(shift.shape)}")
+    b, c, H, W = img.shape
+    out = torch.empty_like(img)
+    with torch.cuda.device(img.device):
+        _check(lib.hrn_lanczos_shift(_ptr(img), _ptr(shift), b, c, H, W, _ptr(out), _stream()), "hrn_lanczos_shift")
+    return out

@@ -1,0 +1,77 @@
+// Shared device/host helpers for the gfx950 HighRes-net kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define HRN_F32 0
+#define HRN_BF16 1
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ------------------------------------------------------------------ error plumbing (host)
+void hrn_set_error(const char* fmt, ...);
+#define HRN_CHECK(cond, code, ...)                                \
+    do {                                                          \
+        if (!(cond)) { hrn_set_error(__VA_ARGS__); return (code); } \
+    } while (0)
+#define HRN_HIP(call)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            hrn_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -5;                                                                   \
+        }                                                                                \
+    } while (0)
+#define HRN_LAUNCH_CHECK()  HRN_HIP(hipGetLastError())
+
+// ------------------------------------------------------------------ bf16 helpers (device)
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned)b) << 16);
+}
+// round-to-nearest-even via the hardware convert (v_cvt_pk_bf16_f32 on gfx950, NaN-safe)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+}
+
+template <int DT> struct ElemOf;
+template <> struct ElemOf<HRN_F32>  { typedef float type;          static constexpr int size = 4; };
+template <> struct ElemOf<HRN_BF16> { typedef unsigned short type; static constexpr int size = 2; };
+
+template <int DT> __device__ __forceinline__ float load_elem(const void* p, size_t i);
+template <> __device__ __forceinline__ float load_elem<HRN_F32>(const void* p, size_t i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float load_elem<HRN_BF16>(const void* p, size_t i) { return bf16_bits_to_f32(((const unsigned short*)p)[i]); }
+
+template <int DT> __device__ __forceinline__ void store_elem(void* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_elem<HRN_F32>(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ __forceinline__ void store_elem<HRN_BF16>(void* p, size_t i, float v) { ((unsigned short*)p)[i] = f32_to_bf16_bits(v); }
+
+// 4 consecutive elements (16-byte aligned for f32, 8-byte aligned for bf16)
+template <int DT> __device__ __forceinline__ f32x4 load4(const void* p, size_t i);
+template <> __device__ __forceinline__ f32x4 load4<HRN_F32>(const void* p, size_t i) {
+    return *(const f32x4*)((const float*)p + i);
+}
+template <> __device__ __forceinline__ f32x4 load4<HRN_BF16>(const void* p, size_t i) {
+    uint2 u = *(const uint2*)((const unsigned short*)p + i);
+    f32x4 r;
+    r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xffff0000u);
+    r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+template <int DT> __device__ __forceinline__ void store4(void* p, size_t i, f32x4 v);
+template <> __device__ __forceinline__ void store4<HRN_F32>(void* p, size_t i, f32x4 v) {
+    *(f32x4*)((float*)p + i) = v;
+}
+template <> __device__ __forceinline__ void store4<HRN_BF16>(void* p, size_t i, f32x4 v) {
+    uint2 u; u.x = pack2_bf16(v[0], v[1]); u.y = pack2_bf16(v[2], v[3]);
+    *(uint2*)((unsigned short*)p + i) = u;
+}
+
+static inline size_t hrn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int hrn_esize(int dt) { return dt == HRN_BF16 ? 2 : 4; }

@@ -1,0 +1,34 @@
+// Internal launcher declarations (one per kernel family).  All launch asynchronously on `stream`, allocate
+// nothing and never synchronise (graph-capturable); they return 0 or a negative error with hrn_set_error() set.
+#pragma once
+#include "common.h"
+#include "conv3x3.h"
+
+// ---- stem.hip
+int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, hipStream_t stream);
+int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1,
+                    const float* sub, const float* w, const float* bias, const float* slope, void* out,
+                    int M, int H, int W, hipStream_t stream);
+int hrn_launch_plane_mean(const float* x, float* mean, int planes, size_t hw, hipStream_t stream);
+
+// ---- decoder.hip
+// fused [N][HW][64] (dt) -> sr [N][3H][3W] f32.  wpk: packed deconv weights (hrn_launch_decoder_pack), bias/slope/wf/bf f32.
+int hrn_launch_decoder(int dt, const void* fused, const void* wpk, const float* bias, const float* slope,
+                       const float* wf, const float* bf, float* sr, int N, int H, int W, hipStream_t stream);
+int hrn_launch_decoder_pack(int dt, const float* w_iokk, void* packed, hipStream_t stream);
+
+// ---- lanczos.hip
+int hrn_launch_lanczos_taps(const float* d, int n, float* taps, hipStream_t stream);
+int hrn_launch_lanczos_shift(const float* img, const float* shift, int b, int c, int H, int W, float* out, hipStream_t stream);
+
+// ---- shiftnet.hip
+int hrn_launch_bn_stats(const float* x, size_t npix, int C, const float* gamma, const float* beta, float eps,
+                        float* scale, float* shift, float* running_mean, float* running_var, float momentum,
+                        double* partial, int partial_blocks, hipStream_t stream);
+int hrn_launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                       const float* conv_bias, float* scale, float* shift, int C, hipStream_t stream);
+int hrn_launch_bn_act_pool(const float* x, const float* scale, const float* shift, float* out, int N, int H, int W, int C,
+                           int pool, hipStream_t stream);
+int hrn_launch_fc1(const float* x, const float* w, const float* b, const unsigned char* mask, float* y, int B, hipStream_t stream);
+int hrn_launch_fc2(const float* y, const float* w, float* theta, int B, hipStream_t stream);
+int hrn_launch_fc1_pack(const float* w, float* packed, hipStream_t stream);

@@ -1,0 +1,168 @@
+// Reference frame (per-pixel lower median) and the 2->64 stem convolution.
+//
+//   median : /root/reference/src/DeepNetworks/HRNet.py:200   torch.median(lrs[:, :9], 1)  (lower middle, pads included)
+//   stem   : HRNet.py:201-204 (repeat / cat / view are never materialised) + :51-53 conv(2->64)+PReLU
+//            ShiftNet.py:58 (per-plane mean subtraction) + :16 conv(2->64)   (BatchNorm/ReLU applied by bn_act kernel)
+//
+// Both are HBM-bound (stem: 8 B read, 128/256 B written per pixel); the conv runs on the fp32 VALU so the raw
+// uint16-range image values never pass through bf16.
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void cswap(float& a, float& b) {
+    const float lo = fminf(a, b), hi = fmaxf(a, b);
+    a = lo; b = hi;
+}
+
+// lrs [B][V][HW] f32 -> ref [B][HW] f32
+__global__ void median_kernel(const float* __restrict__ lrs, float* __restrict__ ref, int V, size_t hw, size_t total) {
+    const int n = V < 9 ? V : 9;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = idx / hw, pix = idx - b * hw;
+        const float* src = lrs + b * V * hw + pix;
+        float v[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v[i] = i < n ? src[(size_t)i * hw] : __builtin_inff();
+        // optimal 25-exchange / 7-layer sorting network for 9 keys (verified exhaustively by the 0-1 principle in
+        // tests/test_host_logic.py); +inf padding sinks to the end so index (n-1)/2 is the lower median of n keys
+        cswap(v[0], v[3]); cswap(v[1], v[7]); cswap(v[2], v[5]); cswap(v[4], v[8]);
+        cswap(v[0], v[7]); cswap(v[2], v[4]); cswap(v[3], v[8]); cswap(v[5], v[6]);
+        cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+        cswap(v[1], v[4]); cswap(v[3], v[6]); cswap(v[5], v[7]);
+        cswap(v[0], v[1]); cswap(v[2], v[4]); cswap(v[3], v[5]); cswap(v[6], v[8]);
+        cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+        cswap(v[1], v[2]); cswap(v[3], v[4]); cswap(v[5], v[6]);
+        const int k = (n - 1) >> 1;     // lower median
+        float out = v[0];
+#pragma unroll
+        for (int i = 1; i < 9; ++i) out = (i == k) ? v[i] : out;
+        ref[idx] = out;
+    }
+}
+
+// One thread = 4 consecutive pixels (along x) x 16 output channels.  Block = 256 threads = 64 pixel-quads x 4 channel groups.
+// weights w [64][2][3][3] f32 (OIHW) staged transposed in LDS as wl[ci*9+tap][64].
+template <int DT>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                   size_t img_stride0, int rep1, size_t img_stride1,
+                                                   const float* __restrict__ sub,   // [M][2] per-plane means or null
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   const float* __restrict__ slope, void* __restrict__ out,
+                                                   int M, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float wl[18 * 64];
+    __shared__ float bl[64];
+    for (int i = threadIdx.x; i < 18 * 64; i += 256) {
+        const int co = i & 63, k = i >> 6;           // k = ci*9 + tap
+        wl[i] = w[co * 18 + k];
+    }
+    if (threadIdx.x < 64) bl[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const float a = slope ? slope[0] : 1.f;
+    const int cg = threadIdx.x & 3;                  // channel group: couts cg*16 .. +15
+    const int wq = (W + 3) >> 2;
+    const size_t quads = (size_t)M * H * wq;
+    for (size_t qi = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); qi < quads; qi += (size_t)gridDim.x * 64) {
+        const int xq = (int)(qi % wq);
+        const int y = (int)((qi / wq) % H);
+        const int m = (int)(qi / ((size_t)wq * H));
+        const int x0 = xq * 4;
+        const float* p0 = in0 + (size_t)m * img_stride0;
+        const float* p1 = in1 + (size_t)(m / rep1) * img_stride1;
+        const float s0 = sub ? sub[2 * m] : 0.f, s1 = sub ? sub[2 * m + 1] : 0.f;
+        float win[2][3][6];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int gy = y + dy - 1;
+#pragma unroll
+            for (int dx = 0; dx < 6; ++dx) {
+                const int gx = x0 + dx - 1;
+                const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                win[0][dy][dx] = ok ? p0[(size_t)gy * W + gx] - s0 : 0.f;
+                win[1][dy][dx] = ok ? p1[(size_t)gy * W + gx] - s1 : 0.f;
+            }
+        }
+        float acc[4][16];
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[px][c] = bl[cg * 16 + c];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* wr = wl + (ci * 9 + dy * 3 + dx) * 64 + cg * 16;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const f32x4 wv = *(const f32x4*)(wr + c4 * 4);
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) {
+                            const float xin = win[ci][dy][dx + px];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[px][c4 * 4 + j] = fmaf(xin, wv[j], acc[px][c4 * 4 + j]);
+                        }
+                    }
+                }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            if (x0 + px >= W) continue;
+            const size_t o = (((size_t)m * H + y) * W + x0 + px) * 64 + cg * 16;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = acc[px][c4 * 4 + j];
+                    v[j] = t >= 0.f ? t : a * t;
+                }
+                store4<DT>(out, o + c4 * 4, v);
+            }
+        }
+    }
+}
+
+// per-plane mean: x [planes][hw] -> mean[planes]   (ShiftNet.py:58)
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ mean, size_t hw) {
+    const float* p = x + (size_t)blockIdx.x * hw;
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < hw; i += 256) s += (double)p[i];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[blockIdx.x] = (float)(red[0] / (double)hw);
+}
+
+}  // namespace
+
+int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, hipStream_t stream) {
+    const size_t hw = (size_t)H * W, total = (size_t)B * hw;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, stream, lrs, ref, V, hw, total);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1,
+                    const float* sub, const float* w, const float* bias, const float* slope, void* out,
+                    int M, int H, int W, hipStream_t stream) {
+    const size_t quads = (size_t)M * H * ((W + 3) / 4);
+    const int blocks = (int)((quads + 63) / 64 < 8192 ? (quads + 63) / 64 : 8192);
+    if (dt == HRN_BF16)
+        hipLaunchKernelGGL(stem_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W);
+    else
+        hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_plane_mean(const float* x, float* mean, int planes, size_t hw, hipStream_t stream) {
+    hipLaunchKernelGGL(plane_mean_kernel, dim3(planes), dim3(256), 0, stream, x, mean, hw);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}

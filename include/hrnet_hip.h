@@ -1,0 +1,127 @@
+/* hrnet_hip.h - C ABI of libhrnet_hip.so: the MI355X (gfx950) implementation of the HighRes-net hot path.
+ *
+ * The reference (gwall-ceres/HighRes-net) has no FFI: its boundary is three Python symbols.  Every entry point
+ * below replaces one of them (or one stage of one); `highres-net_amd/hrnet_hip/binding.py` binds them with
+ * ctypes and `highres-net_amd/{DeepNetworks/HRNet.py,DeepNetworks/ShiftNet.py,lanczos.py}` re-expose the
+ * reference's module names on top.
+ *
+ *   hrn_hrnet_forward      <-  HRNet.forward(lrs, alphas)            src/DeepNetworks/HRNet.py:186-211
+ *   hrn_encoder_forward    <-  median/stack + Encoder.forward         src/DeepNetworks/HRNet.py:200-206, :62-74
+ *   hrn_fuse_forward       <-  RecuversiveNet.forward                 src/DeepNetworks/HRNet.py:99-134
+ *   hrn_decoder_forward    <-  Decoder.forward                        src/DeepNetworks/HRNet.py:158-169
+ *   hrn_shiftnet_forward   <-  ShiftNet.forward(x)                    src/DeepNetworks/ShiftNet.py:49-75
+ *   hrn_lanczos_shift      <-  lanczos.lanczos_shift(img, shift, ...) src/lanczos.py:47-107
+ *                              (and ShiftNet.transform, ShiftNet.py:77-90, which only re-labels its arguments)
+ *   hrn_lanczos_kernel     <-  lanczos.lanczos_kernel(dx, a=3, N=7)   src/lanczos.py:5-43
+ *   hrn_*_pack             <-  nn.Module.load_state_dict / .to(device): reference-layout f32 parameters
+ *                              (OIHW conv, (Cin,Cout,kH,kW) deconv, (out,in) linear) -> kernel layouts
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed or a torch CUDA tensor's data_ptr) unless stated;
+ *     all tensors are dense / contiguous; images are square-agnostic here (the Python mirror asserts H == W
+ *     where the reference's .view() does, HRNet.py:204);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work: no allocation,
+ *     no synchronisation, no host read-back, so a call sequence can be captured into a hipGraph;
+ *   - the caller owns every buffer, including the workspace (size from the matching *_workspace_bytes);
+ *   - return value: 0 on success, negative on error (-2 bad argument, -3 workspace/packed buffer too small,
+ *     -5 HIP runtime error); hrn_last_error() returns a thread-local message for the last failing call;
+ *   - dtype selects storage of activations and the MFMA input type:
+ *       HRN_DTYPE_F32  : f32 activations, v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation)
+ *       HRN_DTYPE_BF16 : bf16 activations/weights, v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ *     inputs (lrs, alphas, ShiftNet pairs, Lanczos images) and the SR output are always f32.
+ */
+#ifndef HRNET_HIP_H
+#define HRNET_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HRN_DTYPE_F32 0
+#define HRN_DTYPE_BF16 1
+#define HRN_MAX_RES_LAYERS 8
+#define HRN_ABI_VERSION 1
+
+int hrn_version(void);
+const char* hrn_last_error(void);
+
+/* ------------------------------------------------------------------ HRNet */
+/* Parameters exactly as the reference's state_dict holds them (f32, contiguous). */
+typedef struct hrn_hrnet_params {
+    int num_layers;                                   /* config["encoder"]["num_layers"], 0..HRN_MAX_RES_LAYERS */
+    const float* enc_init_w;                          /* encode.init_layer.0.weight (64,2,3,3) */
+    const float* enc_init_b;                          /* encode.init_layer.0.bias   (64)       */
+    const float* enc_init_a;                          /* encode.init_layer.1.weight (1)  PReLU */
+    const float* enc_res_w[2 * HRN_MAX_RES_LAYERS];   /* encode.res_layers.L.block.{0,2}.weight (64,64,3,3), index 2L+{0,1} */
+    const float* enc_res_b[2 * HRN_MAX_RES_LAYERS];   /* ... .bias (64) */
+    const float* enc_res_a[2 * HRN_MAX_RES_LAYERS];   /* encode.res_layers.L.block.{1,3}.weight (1) */
+    const float* enc_final_w;                         /* encode.final.0.weight (64,64,3,3) */
+    const float* enc_final_b;                         /* encode.final.0.bias */
+    const float* fuse_res_w[2];                       /* fuse.fuse.0.block.{0,2}.weight (128,128,3,3) */
+    const float* fuse_res_b[2];
+    const float* fuse_res_a[2];                       /* fuse.fuse.0.block.{1,3}.weight (1) */
+    const float* fuse_out_w;                          /* fuse.fuse.1.weight (64,128,3,3) */
+    const float* fuse_out_b;
+    const float* fuse_out_a;                          /* fuse.fuse.2.weight (1) */
+    const float* dec_w;                               /* decode.deconv.0.weight (64,64,3,3) = (Cin,Cout,kH,kW) */
+    const float* dec_b;
+    const float* dec_a;                               /* decode.deconv.1.weight (1) */
+    const float* fin_w;                               /* decode.final.weight (1,64,1,1) */
+    const float* fin_b;                               /* decode.final.bias (1) */
+} hrn_hrnet_params;
+
+size_t hrn_hrnet_packed_bytes(int dtype, int num_layers);
+int hrn_hrnet_pack(const hrn_hrnet_params* params, int dtype, void* packed, size_t packed_bytes, void* stream);
+
+size_t hrn_hrnet_workspace_bytes(int dtype, int B, int V, int H, int W);
+
+/* lrs (B,V,H,W) f32, alphas (B,V) f32 -> sr (B,1,3H,3W) f32 */
+int hrn_hrnet_forward(const void* packed, int dtype, int num_layers, int alpha_residual,
+                      const float* lrs, const float* alphas, int B, int V, int H, int W,
+                      float* sr, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stages (same workspace).  emb: view stack [B][V][H][W][64] in `dtype` (channels-last); fused: [B][H][W][64]. */
+int hrn_encoder_forward(const void* packed, int dtype, int num_layers, const float* lrs, int B, int V, int H, int W,
+                        void* emb, void* workspace, size_t workspace_bytes, void* stream);
+/* Destroys `emb` (levels are reduced in place, HRNet.py:113-132). */
+int hrn_fuse_forward(const void* packed, int dtype, int num_layers, int alpha_residual, void* emb, const float* alphas,
+                     int B, int V, int H, int W, void* fused, void* workspace, size_t workspace_bytes, void* stream);
+int hrn_decoder_forward(const void* packed, int dtype, int num_layers, const void* fused, int N, int H, int W,
+                        float* sr, void* stream);
+
+/* ------------------------------------------------------------------ ShiftNet */
+typedef struct hrn_shiftnet_params {
+    const float* conv_w[8];       /* layerN.0.weight  (co,ci,3,3): 2->64,64->64 x3,64->128,128->128 x3 */
+    const float* conv_b[8];       /* layerN.0.bias */
+    const float* bn_g[8];         /* layerN.1.weight */
+    const float* bn_b[8];         /* layerN.1.bias */
+    float* bn_rm[8];              /* layerN.1.running_mean (updated in place when train_bn != 0) */
+    float* bn_rv[8];              /* layerN.1.running_var  (updated in place when train_bn != 0) */
+    const float* fc1_w;           /* fc1.weight (1024, 32768), reference flatten order c*256 + h*16 + w */
+    const float* fc1_b;           /* fc1.bias (1024) */
+    const float* fc2_w;           /* fc2.weight (2, 1024) */
+} hrn_shiftnet_params;
+
+size_t hrn_shiftnet_packed_bytes(void);
+int hrn_shiftnet_pack(const hrn_shiftnet_params* params, void* packed, size_t packed_bytes, void* stream);
+size_t hrn_shiftnet_workspace_bytes(int B);
+
+/* x (B,2,128,128) f32 -> theta (B,2) f32.  `params` supplies the live BatchNorm tensors (affine + running stats);
+ * its conv/fc pointers are not read here (they live in `packed`).
+ * train_bn != 0: batch statistics (biased var) and running-stat update with `momentum` (nn.BatchNorm2d train mode);
+ * dropout_mask: NULL (eval) or uint8 (B,32768) keep-mask in the reference's flatten order; kept activations x2. */
+int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* params, const float* x, int B,
+                         int train_bn, float momentum, const unsigned char* dropout_mask, float* theta,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ Lanczos */
+/* dx (n) f32 -> taps (n,7) f32;  a = 3, N = 7 (the only values the reference's call sites use). */
+int hrn_lanczos_kernel(const float* dx, int n, float* taps, void* stream);
+/* img (b,c,H,W) f32, shift (c,2) = (dy,dx) per channel -> out (b,c,H,W) f32;  a = 3, N = 7, any p >= 3. */
+int hrn_lanczos_shift(const float* img, const float* shift, int b, int c, int H, int W, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRNET_HIP_H */
