@@ -66,6 +66,10 @@ SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_lanczos_kernel": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_lanczos_shift": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "hrn_profile_enable": (_c.c_int, [_c.c_int]),
+    "hrn_profile_count": (_c.c_int, []),
+    "hrn_profile_get": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_int, _c.POINTER(_c.c_long), _c.POINTER(_c.c_double),
+                                   _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }
 
 _lib = None
@@ -312,4 +316,21 @@ def lanczos_shift(img, shift):
     out = torch.empty_like(img)
     with torch.cuda.device(img.device):
         _check(lib.hrn_lanczos_shift(_ptr(img), _ptr(shift), b, c, H, W, _ptr(out), _stream()), "hrn_lanczos_shift")
+    return out
+
+
+# --------------------------------------------------------------------------- built-in kernel timing
+def profile_enable(on):
+    _check(load_library().hrn_profile_enable(int(bool(on))), "hrn_profile_enable")
+
+
+def profile_read():
+    """-> {family: dict(launches, ms, flops, bytes)} for everything recorded since profile_enable(True)."""
+    lib = load_library()
+    out = {}
+    for i in range(lib.hrn_profile_count()):
+        name = ctypes.create_string_buffer(64)
+        n, ms, fl, by = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(lib.hrn_profile_get(i, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)), "hrn_profile_get")
+        out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
     return out

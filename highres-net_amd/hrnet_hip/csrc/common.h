@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include "prof.h"
 
 #define HRN_F32 0
 #define HRN_BF16 1

@@ -254,6 +254,11 @@ int launch(const ConvParams& p, hipStream_t stream) {
     const long tiles = (long)((p.W + CONV_TILE_W - 1) / CONV_TILE_W) * ((p.H + CONV_TILE_H - 1) / CONV_TILE_H);
     const long nwg = tiles * p.M;
     HRN_CHECK(nwg > 0 && nwg < (1L << 31), -2, "conv3x3: bad grid (%ld workgroups)", nwg);
+    static const char* fam_names[2][2][2] = {{{"conv3x3_f32_64x64", "conv3x3_f32_64x128"}, {"conv3x3_f32_128x64", "conv3x3_f32_128x128"}},
+                                             {{"conv3x3_bf16_64x64", "conv3x3_bf16_64x128"}, {"conv3x3_bf16_128x64", "conv3x3_bf16_128x128"}}};
+    const double px = (double)p.M * p.H * p.W, es = ElemOf<DT>::size;
+    HrnProfScope prof(fam_names[DT][CIN / 128][COUT / 128], 2.0 * CIN * COUT * 9 * px,
+                      px * es * (CIN + COUT + (p.res_mode ? COUT : 0)), stream);
     hipLaunchKernelGGL((conv3x3_kernel<DT, CIN, COUT>), dim3((unsigned)nwg), dim3(256), LDS_BYTES, stream, p);
     HRN_LAUNCH_CHECK();
     return 0;

@@ -175,6 +175,8 @@ int hrn_launch_decoder(int dt, const void* fused, const void* wpk, const float* 
     const size_t npix = (size_t)N * H * W;
     HRN_CHECK(npix > 0, -2, "decoder: empty input");
     const unsigned blocks = (unsigned)((npix + 255) / 256);
+    HrnProfScope prof(dt == HRN_BF16 ? "decoder_bf16" : "decoder_f32", (2.0 * 64 * 576 + 2.0 * 576) * npix,
+                      (double)npix * (64.0 * hrn_esize(dt) + 36.0), stream);
     if (dt == HRN_BF16)
         hipLaunchKernelGGL(decoder_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, fused, wpk, bias, slope, wf, bf, sr, npix, H, W);
     else

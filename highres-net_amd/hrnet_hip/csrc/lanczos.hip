@@ -105,6 +105,7 @@ int hrn_launch_lanczos_shift(const float* img, const float* shift, int b, int c,
     HRN_CHECK((long)b * c <= 65535, -2, "lanczos_shift: b*c = %ld exceeds the grid limit", (long)b * c);
     if (b * c == 0) return 0;
     const int tiles = ((W + LT_W - 1) / LT_W) * ((H + LT_H - 1) / LT_H);
+    HrnProfScope prof("lanczos_shift", 28.0 * b * c * H * W, 8.0 * b * c * H * W, stream);
     hipLaunchKernelGGL(lanczos_shift_kernel, dim3(tiles, b * c), dim3(256), 0, stream, img, shift, out, c, H, W);
     HRN_LAUNCH_CHECK();
     return 0;

@@ -175,6 +175,7 @@ int hrn_launch_bn_stats(const float* x, size_t npix, int C, const float* gamma, 
                         double* partial, int partial_blocks, hipStream_t stream) {
     HRN_CHECK(C == 64 || C == 128, -2, "bn_stats: unsupported channel count %d", C);
     HRN_CHECK(partial_blocks > 0, -2, "bn_stats: no partial buffer");
+    HrnProfScope prof("bn_stats", 0.0, (double)npix * C * 4, stream);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(partial_blocks), dim3(256), 0, stream, x, npix, C, partial);
     HRN_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(128), 0, stream, partial, partial_blocks, npix, C, gamma, beta, eps,
@@ -196,6 +197,7 @@ int hrn_launch_bn_act_pool(const float* x, const float* scale, const float* shif
     HRN_CHECK(!pool || (H % 2 == 0 && W % 2 == 0), -2, "maxpool2 needs even H, W");
     const size_t total = (size_t)N * (H / p) * (W / p) * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    HrnProfScope prof("bn_relu_pool", 0.0, (double)N * H * W * C * 4 * (1.0 + 1.0 / (p * p)), stream);
     if (pool) hipLaunchKernelGGL(bn_act_pool_kernel<2>, dim3(blocks), dim3(256), 0, stream, x, scale, shift, out, N, H, W, C);
     else hipLaunchKernelGGL(bn_act_pool_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, scale, shift, out, N, H, W, C);
     HRN_LAUNCH_CHECK();
@@ -203,6 +205,7 @@ int hrn_launch_bn_act_pool(const float* x, const float* scale, const float* shif
 }
 
 int hrn_launch_fc1(const float* x, const float* w, const float* b, const unsigned char* mask, float* y, int B, hipStream_t stream) {
+    HrnProfScope prof("fc1", 2.0 * B * 1024 * 32768, 1024.0 * 32768 * 4 + (double)B * 32768 * 4, stream);
     hipLaunchKernelGGL(fc1_kernel, dim3(1024), dim3(256), 0, stream, x, w, b, mask, y, B);
     HRN_LAUNCH_CHECK();
     return 0;

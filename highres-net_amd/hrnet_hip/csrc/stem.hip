@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
 int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, hipStream_t stream) {
     const size_t hw = (size_t)H * W, total = (size_t)B * hw;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    HrnProfScope prof("median9", 0.0, (double)total * 4 * ((V < 9 ? V : 9) + 1), stream);
     hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(256), 0, stream, lrs, ref, V, hw, total);
     HRN_LAUNCH_CHECK();
     return 0;
@@ -153,6 +154,8 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
                     int M, int H, int W, hipStream_t stream) {
     const size_t quads = (size_t)M * H * ((W + 3) / 4);
     const int blocks = (int)((quads + 63) / 64 < 8192 ? (quads + 63) / 64 : 8192);
+    const double px = (double)M * H * W;
+    HrnProfScope prof(dt == HRN_BF16 ? "stem2x64_bf16" : "stem2x64_f32", 2.0 * 18 * 64 * px, px * (4 + (double)M / rep1 / M * 4 + 64.0 * hrn_esize(dt)), stream);
     if (dt == HRN_BF16)
         hipLaunchKernelGGL(stem_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W);
     else
@@ -162,6 +165,7 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
 }
 
 int hrn_launch_plane_mean(const float* x, float* mean, int planes, size_t hw, hipStream_t stream) {
+    HrnProfScope prof("plane_mean", 0.0, (double)planes * hw * 4, stream);
     hipLaunchKernelGGL(plane_mean_kernel, dim3(planes), dim3(256), 0, stream, x, mean, hw);
     HRN_LAUNCH_CHECK();
     return 0;

@@ -121,6 +121,14 @@ int hrn_lanczos_kernel(const float* dx, int n, float* taps, void* stream);
 /* img (b,c,H,W) f32, shift (c,2) = (dy,dx) per channel -> out (b,c,H,W) f32;  a = 3, N = 7, any p >= 3. */
 int hrn_lanczos_shift(const float* img, const float* shift, int b, int c, int H, int W, float* out, void* stream);
 
+/* ------------------------------------------------------------------ built-in kernel timing (hipEvent pairs)
+ * The reference has no profiling hooks; these exist so that bench.py can state, live, the
+ * achieved TFLOP/s / GB/s of each kernel family against the gfx950 roofline.  enable(1) clears the table and starts
+ * recording on every subsequent launch; enable(0) stops.  get() synchronises the recorded events (host blocks). */
+int hrn_profile_enable(int on);
+int hrn_profile_count(void);
+int hrn_profile_get(int idx, char* name, int name_len, long* launches, double* total_ms, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,56 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing bench.py relies on (rendezvous on 127.0.0.1, barrier, max-over-ranks
+timing, contiguous batch shards, whole-job frame count)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, os.path.join(%r, "highres-net_amd"))
+    import torch
+    from hrnet_hip import dist as hdist
+    rank, local_rank, ws = hdist.init(backend="gloo")
+    assert ws == 2 and rank in (0, 1)
+    lo, hi = hdist.shard(64, rank, ws)
+    assert (lo, hi) == (rank * 32, rank * 32 + 32)
+    hdist.barrier()
+    elapsed = 1.0 + rank            # rank 1 is the slow one
+    t = hdist.max_over_ranks(elapsed)
+    frames = hdist.sum_over_ranks(hi - lo)
+    assert t == 2.0 and frames == 64.0, (t, frames)
+    try:
+        hdist.shard(33, rank, ws)
+        raise SystemExit("shard must reject a ragged batch")
+    except ValueError:
+        pass
+    hdist.barrier()
+    if rank == 0:
+        print(json.dumps({"value": frames / t, "n_gpus": ws}))
+    hdist.finalize()
+""") % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_plumbing(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    assert '"value": 32.0' in outs[0][0]

@@ -1,0 +1,243 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes -> libhrnet_hip.so), against
+  (1) the fixtures produced by the reference itself (tests/golden, oracle/make_goldens.py),
+  (2) the numpy oracle on fresh seeded inputs (edge shapes), and
+  (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (BASELINE.json north_star: "within 1e-3 rel fp32"):
+  fp32 path : max|hip - ref| / max|ref| <= 1e-3 is the contract; the exact-fp32 MFMA path is additionally held to
+              2e-5 as a regression guard (measured ~2e-6).
+  bf16 path : bf16 storage cannot meet 1e-3; it is held to max-rel <= 4e-2 and PSNR(hip, ref) >= 42 dB
+              (measured ~1e-2 / 50-56 dB) and documented as such in DESIGN.md.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hrnet_np as O
+from oracle import synth, weights
+import util
+
+pytestmark = pytest.mark.gpu
+
+FP32_CONTRACT, FP32_GUARD = 1e-3, 2e-5
+BF16_REL, BF16_PSNR = 4e-2, 42.0
+
+HR_CASES = ["hrnet_b1_v1_s16", "hrnet_b2_v5_s16", "hrnet_b2_v6_s16_pad", "hrnet_b1_v12_s24", "hrnet_b2_v4_s16_noalpha",
+            "hrnet_b1_v32_s32"]
+
+
+def _check(prec, got, want):
+    if prec == "fp32":
+        e = util.rel_err(got, want)
+        assert e <= FP32_CONTRACT and e <= FP32_GUARD, e
+    else:
+        assert util.rel_err(got, want) <= BF16_REL and util.psnr_db(got, want) >= BF16_PSNR, (util.rel_err(got, want), util.psnr_db(got, want))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", HR_CASES)
+def test_hrnet_forward_vs_reference_golden(name, prec):
+    g = util.golden(name)
+    m = util.hip_hrnet(prec, bool(g["alpha_residual"]))
+    with torch.no_grad():
+        sr = m(util.dev(g["lrs"]), util.dev(g["alphas"]))
+    assert sr.shape == g["sr"].shape and sr.dtype == torch.float32
+    _check(prec, sr.cpu().numpy(), g["sr"])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["hrnet_b2_v5_s16", "hrnet_b2_v6_s16_pad", "hrnet_b1_v1_s16"])
+def test_hrnet_stages_vs_reference_golden(name, prec):
+    g = util.golden(name)
+    m = util.hip_hrnet(prec)
+    lrs, alphas = util.dev(g["lrs"]), util.dev(g["alphas"])
+    with torch.no_grad():
+        emb = m.encode_views(lrs)
+        assert tuple(emb.shape) == g["lrs"].shape + (64,)
+        _check(prec, util.nhwc_to_nchw(emb), g["emb"])
+        fused = m.fuse_views(emb, alphas)
+        _check(prec, util.nhwc_to_nchw(fused), g["fused"])
+        gf = torch.from_numpy(g["fused"]).cuda().permute(0, 2, 3, 1).contiguous().to(fused.dtype)
+        _check(prec, m.decode_state(gf).cpu().numpy(), g["sr"])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_hrnet_config1_shape(prec):
+    """BASELINE config 1 (B=4, V=4, 128->384) against the reference's own output."""
+    g = util.golden("hrnet_c1_b4_v4_s128")
+    b, v, s = (int(x) for x in g["shape"])
+    lrs, alphas, _ = synth.make_batch(int(g["seed"]), b, v, s, [int(x) for x in g["n_real"]])
+    with torch.no_grad():
+        sr = util.hip_hrnet(prec)(util.dev(lrs), util.dev(alphas)).cpu().numpy()
+    _check(prec, sr, g["sr"])
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 20), (3, 3, 8), (1, 7, 40), (2, 9, 33), (1, 16, 12)])
+def test_hrnet_edge_shapes_vs_oracle(shape):
+    """Sizes that do not fill the 8x32 tile, odd view counts, tiny images; fp32 path vs the fp64 numpy oracle."""
+    b, v, s = shape
+    lrs, alphas, _ = synth.make_batch(1000 + s, b, v, s, [max(1, v - i) for i in range(b)])
+    want = O.hrnet_forward(lrs, alphas, weights.hrnet_state(1234))
+    with torch.no_grad():
+        sr = util.hip_hrnet("fp32")(util.dev(lrs), util.dev(alphas)).cpu().numpy()
+    assert util.rel_err(sr, want) <= FP32_GUARD
+
+
+def test_hrnet_other_weights_and_layers():
+    """A second weight seed and a non-default encoder depth (num_layers=3 and 0) vs the oracle."""
+    from DeepNetworks.HRNet import HRNet
+    for nl in (0, 3):
+        cfg = {k: dict(v) for k, v in weights.HRNET_CONFIG.items()}
+        cfg["encoder"]["num_layers"] = nl
+        m = HRNet(cfg).cuda().eval()
+        st = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        lrs, alphas, _ = synth.make_batch(77, 2, 4, 16)
+        want = O.hrnet_forward(lrs, alphas, st, num_layers=nl)
+        with torch.no_grad():
+            sr = m(util.dev(lrs), util.dev(alphas)).cpu().numpy()
+        assert util.rel_err(sr, want) <= FP32_GUARD
+
+
+def test_packed_parameters_follow_updates():
+    m = util.hip_hrnet("fp32", seed=99)
+    lrs, alphas, _ = synth.make_batch(5, 1, 2, 16)
+    with torch.no_grad():
+        a = m(util.dev(lrs), util.dev(alphas)).clone()
+        m.decode.final.bias.add_(1.0)                    # in-place update bumps the version -> re-pack
+        b = m(util.dev(lrs), util.dev(alphas))
+        m.decode.final.bias.sub_(1.0)
+    assert torch.allclose(b, a + 1.0, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- full-size properties (BASELINE configs 2/3)
+@pytest.mark.parametrize("prec,b,v", [("bf16", 32, 32), ("fp32", 16, 16)])
+def test_full_size_properties(prec, b, v):
+    """At the metric's size the oracle is too slow; check properties that must hold bit-exactly:
+    determinism, batch independence (a sample alone == the sample inside the batch) and invariance to the content
+    of padded views (alpha = 0, index >= 9 so they are outside the median window and never an 'alice')."""
+    lrs, alphas = synth.fast_batch(3, b, v, 128)
+    n_real = v - 5
+    alphas[:, n_real:] = 0.0
+    lrs[:, n_real:] = 0.0
+    m = util.hip_hrnet(prec)
+    x, a = util.dev(lrs), util.dev(alphas)
+    with torch.no_grad():
+        y0 = m(x, a).clone()
+        y1 = m(x, a).clone()
+        assert torch.equal(y0, y1)
+        assert torch.isfinite(y0).all()
+        one = m(x[5:6].contiguous(), a[5:6].contiguous())
+        assert torch.equal(one[0], y0[5])
+        x2 = x.clone()
+        x2[:, n_real:] = torch.rand_like(x2[:, n_real:])
+        y2 = m(x2, a)
+        assert torch.equal(y2, y0)
+        # alpha really gates: switching the padded views on changes the output
+        a2 = a.clone()
+        a2[:, n_real:] = 1.0
+        assert not torch.equal(m(x2, a2), y0)
+    # a sample of the full-size batch against the oracle would take minutes; a 1-sample fp32 check at V=16 is affordable
+    if prec == "fp32":
+        want = O.hrnet_forward(lrs[:1], alphas[:1], weights.hrnet_state(1234), dtype=np.float32)
+        assert util.rel_err(y0[:1].cpu().numpy(), want) <= 1e-4
+
+
+# ----------------------------------------------------------------------------- ShiftNet
+def test_shiftnet_eval_vs_reference_golden():
+    g = util.golden("shiftnet_eval_b3")
+    m = util.hip_shiftnet()
+    with torch.no_grad():
+        th = m(util.dev(g["x"]))
+    assert th.shape == (3, 2)
+    assert util.rel_err(th.cpu().numpy(), g["theta"]) <= 1e-4
+
+
+def test_shiftnet_train_mode_vs_reference_golden():
+    """Train mode: batch-statistics BatchNorm + the reference run's dropout mask (recovered by make_goldens)."""
+    from hrnet_hip import binding
+    g = util.golden("shiftnet_train_b4")
+    m = util.hip_shiftnet().train()
+    mask = np.unpackbits(g["dropout_mask"], axis=1)[:, :32768].astype(np.uint8)
+    with torch.no_grad():
+        th = binding.shiftnet_forward(m.packed_parameters(), m._named(), util.dev(g["x"]), train_bn=True, momentum=0.1,
+                                      dropout_mask=util.dev(mask))
+    assert util.rel_err(th.cpu().numpy(), g["theta"]) <= 1e-3       # measured 7e-6
+    for i in range(1, 9):
+        bn = getattr(m, f"layer{i}")[1]
+        assert np.abs(bn.running_mean.cpu().numpy() - g[f"layer{i}_running_mean"]).max() < 1e-5
+        assert np.abs(bn.running_var.cpu().numpy() - g[f"layer{i}_running_var"]).max() < 1e-5
+
+
+def test_shiftnet_module_train_mode_runs_and_zero_init():
+    from DeepNetworks.ShiftNet import ShiftNet
+    m = ShiftNet().cuda().train()
+    x = torch.rand(4, 2, 128, 128, device="cuda")
+    with torch.no_grad():
+        th = m(x)
+    assert torch.equal(th, torch.zeros_like(th))          # fc2 is zero-initialised (ShiftNet.py:47)
+    assert int(m.layer3[1].num_batches_tracked) == 1
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            m(torch.rand(1, 2, 64, 64, device="cuda"))
+
+
+# ----------------------------------------------------------------------------- Lanczos
+def test_lanczos_vs_reference_golden():
+    import lanczos
+    g = util.golden("lanczos")
+    taps = lanczos.lanczos_kernel(util.dev(g["d"]))
+    assert taps.shape == (9, 7)
+    assert np.abs(taps.cpu().numpy() - g["taps"]).max() <= 2e-6
+    out = lanczos.lanczos_shift(util.dev(g["img"]), util.dev(g["shift"]), p=3)
+    assert np.abs(out.cpu().numpy() - g["shifted"]).max() <= 5e-6
+    tr = util.hip_shiftnet().transform(util.dev(g["theta"]), util.dev(g["imgs"]))
+    assert tuple(tr.shape) == (1, 1, 5, 48, 48)
+    assert np.abs(tr.cpu().numpy() - g["transformed"]).max() <= 5e-6
+    with pytest.raises(NotImplementedError):
+        lanczos.lanczos_shift(util.dev(g["img"]), util.dev(g["shift"]), a=2)
+
+
+def test_lanczos_full_size_properties():
+    """B=32 SR frames of 384x384 (the training-step shape): zero shift is the identity (to tap rounding), an integer
+    shift is a pure translation away from the border, and the result matches the oracle on one frame."""
+    import lanczos
+    rng = np.random.Generator(np.random.PCG64(8))
+    img = rng.random((1, 32, 384, 384), dtype=np.float32)
+    shift = np.zeros((32, 2), np.float32)
+    shift[1] = (2.0, -1.0)
+    shift[2] = (0.37, -1.6)
+    out = lanczos.lanczos_shift(util.dev(img), util.dev(shift)).cpu().numpy()
+    assert np.abs(out[0, 0] - img[0, 0]).max() < 1e-5
+    assert np.abs(out[0, 1, 8:-8, 8:-8] - img[0, 1, 10:-6, 7:-9]).max() < 1e-5       # out(y,x) = in(y+dy, x+dx)
+    want = O.lanczos_shift(img[:, 2:3], shift[2:3])
+    assert np.abs(out[:, 2:3] - want).max() < 5e-6
+
+
+def test_registration_glue_vs_reference_golden():
+    """register_batch + apply_shifts (train.py:26-63) re-enacted on the new modules, on the reference's own SR output."""
+    g = util.golden("callers")
+    sn = util.hip_shiftnet()
+    srs = util.dev(g["srs2"])
+    hrs = util.dev(g["hrs2"])
+    off = (144 - 128) // 2
+    with torch.no_grad():
+        pairs = torch.cat([hrs[:, off:off + 128, off:off + 128].reshape(-1, 1, 128, 128), srs[:, :, off:off + 128, off:off + 128]], 1)
+        thetas = torch.stack([sn(pairs)], 1)                                   # (B, n_views=1, 2)
+        images = srs.view(-1, 1, 144, 144)
+        new = sn.transform(thetas.view(-1, 2), images, device="cuda").view(-1, 1, 144, 144)[:, 0]
+    assert util.rel_err(thetas.cpu().numpy(), g["shifts"]) <= 1e-4
+    assert np.abs(new.cpu().numpy() - g["shifted2"]).max() <= 2e-5 * max(1.0, np.abs(g["shifted2"]).max())
+
+
+# ----------------------------------------------------------------------------- error behaviour
+def test_errors_are_loud():
+    m = util.hip_hrnet("fp32")
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 2, 8, 16, device="cuda"), torch.ones(1, 2, device="cuda"))      # non-square
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 8, 8), torch.ones(1, 2))                                      # CPU tensors: no fallback
+    m2 = util.hip_hrnet("fp32", seed=5)
+    m2.precision = "fp8"
+    with pytest.raises(ValueError):
+        m2(torch.zeros(1, 2, 8, 8, device="cuda"), torch.ones(1, 2, device="cuda"))
+    m2.precision = "fp32"

@@ -113,3 +113,15 @@ def test_callers_match_reference(golden_dir):
     assert rel_err(theta, g["shifts"][:, 0]) < 1e-4
     shifted = O.shiftnet_transform(g["shifts"][:, 0], g["srs2"])[0, 0]
     assert np.abs(shifted - g["shifted2"]).max() < 2e-5 * max(1.0, np.abs(g["shifted2"]).max())
+
+
+@pytest.mark.parametrize("name", ["hrnet_b2_v5_s16", "hrnet_b2_v4_s16_noalpha", "hrnet_b1_v32_s32"])
+def test_torch_cpu_port_matches_reference(golden_dir, name):
+    """oracle/torch_port.py (the cpu_baseline of bench.py) computes the same forward as the reference."""
+    import torch
+    from oracle import torch_port
+    g = load(golden_dir, name)
+    st = weights.to_torch_state(HST)
+    sr = torch_port.hrnet_forward(torch.from_numpy(g["lrs"]), torch.from_numpy(g["alphas"]), st,
+                                  alpha_residual=bool(g["alpha_residual"])).numpy()
+    assert rel_err(sr, g["sr"]) < 1e-5
