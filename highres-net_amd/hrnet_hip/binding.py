@@ -11,7 +11,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhrnet_hip.so")
+LIB_PATH = os.environ.get("HRNET_HIP_LIB") or os.path.join(_HERE, "libhrnet_hip.so")   # override: A/B-testing a build
 
 F32, BF16 = 0, 1
 MAX_RES_LAYERS = 8

@@ -41,7 +41,11 @@ __global__ void median_kernel(const float* __restrict__ lrs, float* __restrict__
     }
 }
 
-// One thread = 4 consecutive pixels (along x) x 16 output channels.  Block = 256 threads = 64 pixel-quads x 4 channel groups.
+// One thread = 4 pixels in a COLUMN (rows y0..y0+3, one x) x 8 output channels; lane & 7 = channel group, so 8
+// consecutive lanes write one pixel's 64 channels (128 B in bf16) and a wave instruction writes 8 consecutive pixels:
+// every store is a run of full 128-byte lines (the first version gave each lane 16 channels of 4 adjacent pixels and
+// wrote 16 partial lines per instruction: 1.56 ms at c3, 24 % of the HBM rate).  Block = 256 threads = 32 x-positions x
+// 8 channel groups = a 4 x 32 pixel patch; the 3 x 6 x 2 input window of a thread is shared along x through L1.
 // weights w [64][2][3][3] f32 (OIHW) staged transposed in LDS as wl[ci*9+tap][64].
 template <int DT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0
                                                    const float* __restrict__ slope, void* __restrict__ out,
                                                    int M, int H, int W) {
     __shared__ __attribute__((aligned(16))) float wl[18 * 64];
-    __shared__ float bl[64];
+    __shared__ __attribute__((aligned(16))) float bl[64];
     for (int i = threadIdx.x; i < 18 * 64; i += 256) {
         const int co = i & 63, k = i >> 6;           // k = ci*9 + tap
         wl[i] = w[co * 18 + k];
@@ -59,65 +63,74 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0
     if (threadIdx.x < 64) bl[threadIdx.x] = bias[threadIdx.x];
     __syncthreads();
     const float a = slope ? slope[0] : 1.f;
-    const int cg = threadIdx.x & 3;                  // channel group: couts cg*16 .. +15
-    const int wq = (W + 3) >> 2;
-    const size_t quads = (size_t)M * H * wq;
-    for (size_t qi = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); qi < quads; qi += (size_t)gridDim.x * 64) {
-        const int xq = (int)(qi % wq);
-        const int y = (int)((qi / wq) % H);
-        const int m = (int)(qi / ((size_t)wq * H));
-        const int x0 = xq * 4;
+    const int cg = threadIdx.x & 7;                  // channel group: couts cg*8 .. +7
+    const int xl = threadIdx.x >> 3;                 // 0..31
+    const int px_tiles = (W + 31) >> 5, py_tiles = (H + 3) >> 2;
+    const size_t patches = (size_t)M * py_tiles * px_tiles;
+    for (size_t pi = blockIdx.x; pi < patches; pi += gridDim.x) {
+        const int tx = (int)(pi % px_tiles);
+        const int ty = (int)((pi / px_tiles) % py_tiles);
+        const int m = (int)(pi / ((size_t)px_tiles * py_tiles));
+        const int x = tx * 32 + xl, y0 = ty * 4;
         const float* p0 = in0 + (size_t)m * img_stride0;
         const float* p1 = in1 + (size_t)(m / rep1) * img_stride1;
         const float s0 = sub ? sub[2 * m] : 0.f, s1 = sub ? sub[2 * m + 1] : 0.f;
-        float win[2][3][6];
+        float win[2][6][3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int gy = y + dy - 1;
+        for (int dy = 0; dy < 6; ++dy) {
+            const int gy = y0 + dy - 1;
 #pragma unroll
-            for (int dx = 0; dx < 6; ++dx) {
-                const int gx = x0 + dx - 1;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int gx = x + dx - 1;
                 const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
                 win[0][dy][dx] = ok ? p0[(size_t)gy * W + gx] - s0 : 0.f;
                 win[1][dy][dx] = ok ? p1[(size_t)gy * W + gx] - s1 : 0.f;
             }
         }
-        float acc[4][16];
+        float acc[4][8];
 #pragma unroll
-        for (int px = 0; px < 4; ++px)
+        for (int py = 0; py < 4; ++py)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[px][c] = bl[cg * 16 + c];
+            for (int c = 0; c < 8; ++c) acc[py][c] = bl[cg * 8 + c];
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const float* wr = wl + (ci * 9 + dy * 3 + dx) * 64 + cg * 16;
+                    const float* wr = wl + (ci * 9 + dy * 3 + dx) * 64 + cg * 8;
+                    const f32x4 w0 = *(const f32x4*)(wr), w1 = *(const f32x4*)(wr + 4);
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const f32x4 wv = *(const f32x4*)(wr + c4 * 4);
+                    for (int py = 0; py < 4; ++py) {
+                        const float xin = win[ci][py + dy][dx];
 #pragma unroll
-                        for (int px = 0; px < 4; ++px) {
-                            const float xin = win[ci][dy][dx + px];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[px][c4 * 4 + j] = fmaf(xin, wv[j], acc[px][c4 * 4 + j]);
+                        for (int j = 0; j < 4; ++j) {
+                            acc[py][j] = fmaf(xin, w0[j], acc[py][j]);
+                            acc[py][4 + j] = fmaf(xin, w1[j], acc[py][4 + j]);
                         }
                     }
                 }
+        if (x < W) {
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            if (x0 + px >= W) continue;
-            const size_t o = (((size_t)m * H + y) * W + x0 + px) * 64 + cg * 16;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                f32x4 v;
+            for (int py = 0; py < 4; ++py) {
+                if (y0 + py >= H) continue;
+                const size_t o = (((size_t)m * H + y0 + py) * W + x) * 64 + cg * 8;
+                f32x4 v0, v1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float t = acc[px][c4 * 4 + j];
-                    v[j] = t >= 0.f ? t : a * t;
+                    const float t0 = acc[py][j], t1 = acc[py][4 + j];
+                    v0[j] = t0 >= 0.f ? t0 : a * t0;
+                    v1[j] = t1 >= 0.f ? t1 : a * t1;
                 }
-                store4<DT>(out, o + c4 * 4, v);
+                if constexpr (DT == HRN_BF16) {
+                    u32x4 u;
+                    u[0] = pack2_bf16(v0[0], v0[1]); u[1] = pack2_bf16(v0[2], v0[3]);
+                    u[2] = pack2_bf16(v1[0], v1[1]); u[3] = pack2_bf16(v1[2], v1[3]);
+                    *(u32x4*)((unsigned short*)out + o) = u;
+                } else {
+                    *(f32x4*)((float*)out + o) = v0;
+                    *(f32x4*)((float*)out + o + 4) = v1;
+                }
             }
         }
     }
@@ -152,8 +165,8 @@ int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, 
 int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1,
                     const float* sub, const float* w, const float* bias, const float* slope, void* out,
                     int M, int H, int W, hipStream_t stream) {
-    const size_t quads = (size_t)M * H * ((W + 3) / 4);
-    const int blocks = (int)((quads + 63) / 64 < 8192 ? (quads + 63) / 64 : 8192);
+    const size_t patches = (size_t)M * ((H + 3) / 4) * ((W + 31) / 32);
+    const int blocks = (int)(patches < 16384 ? patches : 16384);
     const double px = (double)M * H * W;
     HrnProfScope prof(dt == HRN_BF16 ? "stem2x64_bf16" : "stem2x64_f32", 2.0 * 18 * 64 * px, px * (4 + (double)M / rep1 / M * 4 + 64.0 * hrn_esize(dt)), stream);
     if (dt == HRN_BF16)
