@@ -136,6 +136,112 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0
     }
 }
 
+// bf16 storage path: the same 2->64 conv on the matrix cores.  K = 18 is tiny, but the VALU version above issues ~1000
+// instructions per 4 pixels x 8 channels and ran at 1.65 ms (24 % of the HBM rate) at c3.  Here each input value is
+// split into two bf16 (hi = bf16(v), lo = bf16(v - hi): ~16 significant bits, so the uint16-range image is not rounded
+// to 8) and the K axis becomes [18 hi | 18 lo | 12 zero] = 48 = three 32x32x16 k-steps with the (bf16) weights repeated
+// for the lo half: D[co][px] = W hi + W lo.  One wave = one 32-pixel row segment x 64 channels = 6 MFMAs; fragments are
+// built in registers straight from the global loads (no LDS for operands); the result is transposed through a
+// wave-private LDS tile so that the NHWC stores are 16 B per lane, 8 lanes per 128-byte pixel line.
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                        size_t img_stride0, int rep1, size_t img_stride1,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ slope, unsigned short* __restrict__ out,
+                                                        int M, int H, int W) {
+    constexpr int SROW = 144;                                        // staged pixel row: 64 bf16 + 16 B pad
+    __shared__ __attribute__((aligned(16))) unsigned char stg_all[4 * 32 * SROW];
+    __shared__ __attribute__((aligned(16))) float bl[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    if (tid < 64) bl[tid] = bias[tid];
+    __syncthreads();
+    const float a = slope ? slope[0] : 1.f;
+    unsigned char* stg = stg_all + wave * 32 * SROW;
+
+    // A operand: lane (r, hh) holds W2[co = cb*32 + r][k = 16 s + 8 hh + j], W2[co][k] = w[co][k mod 18] for k < 36, else 0
+    bf16x8 wa[2][3];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * hh + j;
+                const float v = k < 36 ? w[(cb * 32 + r) * 18 + (k < 18 ? k : k - 18)] : 0.f;
+                wa[cb][s][j] = (__bf16)v;
+            }
+
+    const int segs_x = (W + 31) >> 5;
+    const size_t nseg = (size_t)M * H * segs_x;
+    for (size_t si = (size_t)blockIdx.x * 4 + wave; si < nseg; si += (size_t)gridDim.x * 4) {
+        const int sx = (int)(si % segs_x);
+        const int y = (int)((si / segs_x) % H);
+        const int m = (int)(si / ((size_t)segs_x * H));
+        const int x = sx * 32 + r;
+        const float* p0 = in0 + (size_t)m * img_stride0;
+        const float* p1 = in1 + (size_t)(m / rep1) * img_stride1;
+        // this pixel's 3x3x2 window, split into hi / lo bf16
+        __bf16 hi[18], lo[18];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int gy = y + dy - 1, gx = x + dx - 1;
+                    const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    const float v = ok ? (ci == 0 ? p0 : p1)[(size_t)gy * W + gx] : 0.f;
+                    const __bf16 h = (__bf16)v;
+                    hi[ci * 9 + dy * 3 + dx] = h;
+                    lo[ci * 9 + dy * 3 + dx] = (__bf16)(v - (float)h);
+                }
+        f32x16 acc[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            bf16x8 bq;                                               // B[k = 16 s + 8 hh + j][col = this pixel]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k0 = 16 * s + j, k1 = k0 + 8;              // the two candidates: hh = 0 / hh = 1
+                const __bf16 z = (__bf16)0.f;
+                const __bf16 c0 = k0 < 18 ? hi[k0] : (k0 < 36 ? lo[k0 - 18] : z);
+                const __bf16 c1 = k1 < 18 ? hi[k1] : (k1 < 36 ? lo[k1 - 18] : z);
+                bq[j] = hh ? c1 : c0;
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], bq, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s], bq, acc[1], 0, 0, 0);
+        }
+        // bias + PReLU + bf16 pack into the staging tile [pixel r][channel]
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cb * 32 + 8 * g + 4 * hh;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = acc[cb][4 * g + j] + bl[co + j];
+                    v[j] = t >= 0.f ? t : a * t;
+                }
+                uint2 u;
+                u.x = pack2_bf16(v[0], v[1]);
+                u.y = pack2_bf16(v[2], v[3]);
+                *(uint2*)(stg + r * SROW + co * 2) = u;
+            }
+        // same wave reads back row-major: lane -> (pixel 8 i + lane/8, 16-byte part lane%8): 8 full lines per instruction
+        unsigned short* orow = out + (((size_t)m * H + y) * W + sx * 32) * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = 8 * i + (lane >> 3), part = lane & 7;
+            const u32x4 v = *(const u32x4*)(stg + px * SROW + part * 16);
+            if (sx * 32 + px < W) *(u32x4*)(orow + (size_t)px * 64 + part * 8) = v;
+        }
+    }
+}
+
 // per-plane mean: x [planes][hw] -> mean[planes]   (ShiftNet.py:58)
 __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ mean, size_t hw) {
     const float* p = x + (size_t)blockIdx.x * hw;
@@ -169,7 +275,12 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
     const int blocks = (int)(patches < 16384 ? patches : 16384);
     const double px = (double)M * H * W;
     HrnProfScope prof(dt == HRN_BF16 ? "stem2x64_bf16" : "stem2x64_f32", 2.0 * 18 * 64 * px, px * (4 + (double)M / rep1 / M * 4 + 64.0 * hrn_esize(dt)), stream);
-    if (dt == HRN_BF16)
+    if (dt == HRN_BF16 && sub == nullptr) {
+        const size_t nseg = (size_t)M * H * ((W + 31) / 32);
+        const int mblocks = (int)((nseg + 3) / 4 < 8192 ? (nseg + 3) / 4 : 8192);
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(mblocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, w, bias, slope,
+                           (unsigned short*)out, M, H, W);
+    } else if (dt == HRN_BF16)
         hipLaunchKernelGGL(stem_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W);
     else
         hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W);
