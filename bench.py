@@ -145,8 +145,19 @@ def main():
         name, v = dom
         achieved = v["flops"] / v["ms"] / 1e9            # TFLOP/s: algorithmic FLOPs of the launches / their summed duration
         peak = PEAK_TFLOPS[args.precision]
+        # HBM bytes per (average) launch come from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
+        # note, + WRITE_SIZE) committed in profiles/r01_traffic.json; null when this run is not that workload
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            w = tj["workload"]
+            if (w["batch"], w["views"], w["size"], w["precision"]) == (args.batch, args.views, args.size, args.precision):
+                traffic = tj["bytes_per_launch"].get(name)
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "bytes_per_launch_algorithmic": v["bytes"] / max(v["launches"], 1),
                     "launches": v["launches"], "avg_launch_ms": round(v["ms"] / max(v["launches"], 1), 4),
                     "flops_per_launch": v["flops"] / max(v["launches"], 1),
                     "algorithmic_gbs": round(v["bytes"] / v["ms"] / 1e6, 1)}

@@ -28,6 +28,7 @@
 // tile after the hand-off barrier; 16-piece residual ring spread over the stages) were correct but slower - a late
 // memory wave stalls the stage barrier for everybody - and are not kept.
 #include "conv3x3.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -52,15 +53,27 @@ struct V3Tile {
     const unsigned char* in_plain;
 };
 
-template <int COUT> struct V3Geom {
+constexpr int TILE_PX = CONV_TILE_H * CONV_TILE_W;          // 256
+
+template <int COUT, bool OFFLOAD> struct V3Geom {
     static constexpr int TPS = COUT == 64 ? 3 : 1;                      // taps per weight stage
     static constexpr int W_BUF_BYTES = TPS * COUT * W_ROW_PITCH;
-    static constexpr int LDS_BYTES = 2 * IN_BUF_BYTES + 2 * W_BUF_BYTES + COUT * 4;
+    // OFFLOAD: bf16 staging tile [256 px][COUT] (+16 B pad per pixel) in the input buffer a finished tile releases;
+    // rows that do not fit it (COUT = 128: 76 of 256) live in a spare region behind the bias
+    static constexpr int SP = COUT * 2 + 16;
+    static constexpr int SROWS_IN = IN_BUF_BYTES / SP < TILE_PX ? IN_BUF_BYTES / SP : TILE_PX;
+    static constexpr int SPARE_BYTES = OFFLOAD ? (TILE_PX - SROWS_IN) * SP : 0;
+    static constexpr int LDS_BYTES = 2 * IN_BUF_BYTES + 2 * W_BUF_BYTES + COUT * 4 + SPARE_BYTES;
 };
 
-template <int CIN, int COUT>
+// OFFLOAD = true: the compute waves end a tile with bias + PReLU (+ residual, COUT = 64) + ONE bf16 rounding into an LDS
+// staging tile, and the INPUT waves - which never load anything for it, so they are never late for a stage barrier -
+// copy it out as 16-byte-per-lane, full-128-byte-line stores while the next tile is already being multiplied.
+// OFFLOAD = false: the compute waves run the whole epilogue themselves (used for COUT = 128 layers with a residual,
+// whose 64 residual registers per lane do not fit next to 128 accumulators).
+template <int CIN, int COUT, bool OFFLOAD>
 __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) {
-    typedef V3Geom<COUT> GEO;
+    typedef V3Geom<COUT, OFFLOAD> GEO;
     constexpr int ES = 2;
     constexpr int NCHUNK = CIN / 64;
     constexpr int NCB = COUT / 32;                          // cout blocks per compute wave (all of COUT)
@@ -113,6 +126,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
         c.in_plain = (const unsigned char*)p.in + (size_t)c.m * hw * CIN * ES;
         return c;
     };
+    // OFFLOAD staging: pixel row of the tile -> LDS address (rows beyond SROWS_IN live in the spare region)
+    constexpr int SP = GEO::SP;
+    constexpr int SROWS_IN = GEO::SROWS_IN;
+    unsigned char* spare_lds = (unsigned char*)(bias_lds + COUT);
+    auto stage_row = [&](unsigned char* stg0, int row) __attribute__((always_inline)) -> unsigned char* {
+        if constexpr (SROWS_IN >= TILE_PX) return stg0 + row * SP;
+        else return row < SROWS_IN ? stg0 + row * SP : spare_lds + (row - SROWS_IN) * SP;
+    };
+    (void)stage_row; (void)spare_lds;
 
     if (tid < COUT) bias_lds[tid] = p.bias[tid];
 
@@ -145,6 +167,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
                 if (cc < N_IN_PIECES) *(u32x4*)(dst + (cc >> 3) * PIX_PITCH + (cc & 7) * 16) = reg[it];
             }
         };
+        // ---- OFFLOAD store duty.  A finished tile's staging tile is complete after the FIRST barrier of the next phase and
+        // has to be gone before this wave's own input commit at the end of that phase (same buffer).  Its NSP 16-byte
+        // pieces per thread are spread over the NSLOT = NST-1 stages in between; a piece is one ds_read_b128 and one
+        // global store (8 lanes per 128-byte pixel line) - no loads, so this wave is never late for a stage barrier.
+        constexpr int PPP = COUT / 8;                           // 16-byte pieces per staged pixel
+        constexpr int NSP = TILE_PX * PPP / LOADER_THREADS;     // pieces per thread and tile (16 / 32)
+        constexpr int NSLOT = NST - 1;
+        constexpr int QS = (NSP + NSLOT - 1) / NSLOT;           // pieces per slot
+        struct Duty { int y0, x0; unsigned char* outp; };
+        auto make_duty = [&](int tli) __attribute__((always_inline)) {
+            Duty d;
+            const V3Tile c = make_tile(slot + (long)tli * G);
+            size_t out_img = (size_t)c.m;
+            if (p.out_h > 0) { const int b = c.m / p.out_h, i = c.m - b * p.out_h; out_img = (size_t)b * p.out_vs + i; }
+            d.outp = (unsigned char*)p.out + out_img * hw * COUT * ES;
+            d.y0 = c.y0; d.x0 = c.x0;
+            return d;
+        };
+        auto store_slot = [&](const Duty& d, unsigned char* stg0, int k) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < QS; ++i) {
+                const int j = k * QS + i;
+                if (j < NSP) {
+                    const int idx = lt + j * LOADER_THREADS;
+                    const int pixel = idx / PPP, part = idx - pixel * PPP;
+                    const int gy = d.y0 + (pixel >> 5), gx = d.x0 + (pixel & 31);
+                    const u32x4 v = *(const u32x4*)(stage_row(stg0, pixel) + part * 16);
+                    if (gy < H && gx < W) *(u32x4*)(d.outp + (((size_t)gy * W + gx) * COUT + part * 8) * ES) = v;
+                }
+            }
+        };
         const long nphase = (long)ntl * NCHUNK;
         issue(0);
         commit(0);
@@ -152,11 +205,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
         for (long ph = 0; ph < nphase; ++ph) {
             const bool more = ph + 1 < nphase;
             if (more) issue(ph + 1);                        // in flight during the whole phase
-#pragma unroll 1
+            const bool duty = OFFLOAD && ph > 0 && ph % NCHUNK == 0;   // the tile that ended with phase ph-1 is drained now
+            Duty d = {0, 0, nullptr};
+            if (duty) d = make_duty((int)(ph / NCHUNK) - 1);
+            unsigned char* stg0 = in_lds + (int)((ph - 1) & 1) * IN_BUF_BYTES;
+#pragma unroll
             for (int st = 0; st < NST; ++st) {
                 if (st == NST - 1 && more) commit((int)((ph + 1) & 1));     // buffer released at the end of phase ph-1
                 lds_done_then_barrier();
+                if constexpr (OFFLOAD) {
+                    if (st < NSLOT && duty) store_slot(d, stg0, st);
+                }
             }
+        }
+        if constexpr (OFFLOAD) {
+            lds_done_then_barrier();                        // final barrier: the last tile is staged
+            const Duty d = make_duty(ntl - 1);
+            unsigned char* stg0 = in_lds + (int)((nphase - 1) & 1) * IN_BUF_BYTES;
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) store_slot(d, stg0, k);
         }
         return;
     }
@@ -195,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
             if (g + 2 < nstage_total) commit(ra, 0);
             lds_done_then_barrier();                        // ends stage g+1
         }
+        if constexpr (OFFLOAD) lds_done_then_barrier();     // final barrier (last tile staged)
         return;
     }
 
@@ -216,8 +284,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-#pragma unroll 1
+        // OFFLOAD, COUT = 64: this tile's residual quads (the accumulator layout: 4 channels of one pixel per quad) are
+        // fetched at the start of the tile's LAST phase, a whole phase (>= 3 stages) before the staging step adds them
+        constexpr bool OFF_RES = OFFLOAD && COUT == 64;
+        u32x2 resq[OFF_RES ? 16 : 1];
+        float res_alpha = 1.f;
+
+        constexpr int UNROLL_CHUNKS = OFFLOAD ? NCHUNK : 1;
+#pragma unroll UNROLL_CHUNKS
         for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+            if constexpr (OFF_RES) {
+                if (chunk == NCHUNK - 1 && p.res_mode != 0) {
+                    const V3Tile c = make_tile(slot + (long)tl_i * G);
+                    const unsigned char* rbase = (const unsigned char*)p.res + (size_t)c.m * hw * 64 * ES;     // res_mode 1
+                    if (p.res_mode == 3) {
+                        const int b = c.m / p.out_h, i = c.m - b * p.out_h;
+                        if (p.alphas) res_alpha = p.alphas[(size_t)b * p.alpha_vs + (p.pair_last - i)];
+                        rbase = (const unsigned char*)p.res + ((size_t)b * p.res_vs + i) * hw * 64 * ES;
+                    }
+                    const int gx = c.x0 + r, gxc = gx < W ? gx : W - 1;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int pb = q >> 3, co = ((q >> 2) & 1) * 32 + 8 * (q & 3) + 4 * hh;
+                        const int gy = c.y0 + 2 * wave + pb, gyc = gy < H ? gy : H - 1;       // clamped: loads are unconditional
+                        resq[q] = *(const u32x2*)(rbase + (((size_t)gyc * W + gxc) * 64 + co) * ES);
+                    }
+                }
+            }
             const unsigned char* xin = in_lds + (int)(gphase & 1) * IN_BUF_BYTES + b_off;
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
@@ -258,6 +351,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
             ++gphase;
         }
 
+        if constexpr (OFFLOAD) {
+            // ---- tile done: bias + PReLU (+ residual) -> one bf16 rounding -> staging tile (the input buffer this tile has
+            // just released).  The INPUT waves store it after the next barrier while these waves multiply the next tile.
+            unsigned char* stg0 = in_lds + (int)((gphase - 1) & 1) * IN_BUF_BYTES;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                unsigned char* rowp = stage_row(stg0, (2 * wave + pb) * 32 + r);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = cb * 32 + 8 * g + 4 * hh;
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[cb][pb][4 * g + j];
+                        v += *(const f32x4*)(bias_lds + co);
+                        if (has_slope) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] >= 0.f ? v[j] : slope * v[j];
+                        }
+                        if constexpr (OFF_RES) {
+                            if (p.res_mode != 0) {
+                                const u32x2 rq = resq[pb * 8 + cb * 4 + g];
+                                f32x4 rr;
+                                rr[0] = __uint_as_float(rq[0] << 16); rr[1] = __uint_as_float(rq[0] & 0xffff0000u);
+                                rr[2] = __uint_as_float(rq[1] << 16); rr[3] = __uint_as_float(rq[1] & 0xffff0000u);
+                                v = p.res_mode == 3 ? rr + res_alpha * v : v + rr;
+                            }
+                        }
+                        u32x2 u;
+                        u[0] = pack2_bf16(v[0], v[1]);
+                        u[1] = pack2_bf16(v[2], v[3]);
+                        *(u32x2*)(rowp + co * 2) = u;
+                    }
+                }
+            }
+        } else
         // ---- epilogue: bias, PReLU, residual, NHWC store
         {
             const V3Tile cur = make_tile(slot + (long)tl_i * G);
@@ -335,17 +465,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
             }
         }
     }
+    if constexpr (OFFLOAD) lds_done_then_barrier();         // final barrier: hands the last staging tile to the INPUT waves
 }
 
 int g_v3_cus = 0;
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool OFFLOAD>
 int launch_v3(const ConvParams& p, hipStream_t stream) {
-    constexpr int LDS_BYTES = V3Geom<COUT>::LDS_BYTES;
+    constexpr int LDS_BYTES = V3Geom<COUT, OFFLOAD>::LDS_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        HRN_HIP(hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HRN_HIP(hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CIN, COUT, OFFLOAD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     if (g_v3_cus == 0) {
@@ -361,9 +492,10 @@ int launch_v3(const ConvParams& p, hipStream_t stream) {
     if (total < grid) grid = total;
     if (grid >= 8) grid &= ~7L;
     static const char* fam = CIN == 64 ? "conv3x3_bf16_64x64" : (COUT == 64 ? "conv3x3_bf16_128x64" : "conv3x3_bf16_128x128");
+    static const char* fam_res = CIN == 64 ? "conv3x3_bf16_64x64+res" : (COUT == 64 ? "conv3x3_bf16_128x64+res" : "conv3x3_bf16_128x128+res");
     const double px = (double)p.M * p.H * p.W;
-    HrnProfScope prof(fam, 2.0 * CIN * COUT * 9 * px, px * 2 * (CIN + COUT + (p.res_mode ? COUT : 0)), stream);
-    hipLaunchKernelGGL((conv3x3_v3_kernel<CIN, COUT>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
+    HrnProfScope prof(p.res_mode ? fam_res : fam, 2.0 * CIN * COUT * 9 * px, px * 2 * (CIN + COUT + (p.res_mode ? COUT : 0)), stream);
+    hipLaunchKernelGGL((conv3x3_v3_kernel<CIN, COUT, OFFLOAD>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -373,8 +505,13 @@ int launch_v3(const ConvParams& p, hipStream_t stream) {
 // bf16, no folded scale / ReLU (HRNet layers).  Returns -100 when the shape is not covered (caller falls back).
 int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t stream) {
     if (p.scale || p.relu) return -100;
-    if (cin == 64 && cout == 64) return launch_v3<64, 64>(p, stream);
-    if (cin == 128 && cout == 64) return launch_v3<128, 64>(p, stream);
-    if (cin == 128 && cout == 128) return launch_v3<128, 128>(p, stream);
+    // HRN_CONV_OFFLOAD=0 keeps the whole epilogue on the compute waves (A/B timing); default: off-loaded stores wherever
+    // the kernel supports them (every COUT = 64 layer; COUT = 128 layers without a residual)
+    static int offload = -1;
+    if (offload < 0) { const char* e = getenv("HRN_CONV_OFFLOAD"); offload = e ? atoi(e) : 1; }
+    if (cin == 64 && cout == 64) return offload ? launch_v3<64, 64, true>(p, stream) : launch_v3<64, 64, false>(p, stream);
+    if (cin == 128 && cout == 64) return offload ? launch_v3<128, 64, true>(p, stream) : launch_v3<128, 64, false>(p, stream);
+    if (cin == 128 && cout == 128)
+        return (offload && p.res_mode == 0) ? launch_v3<128, 128, true>(p, stream) : launch_v3<128, 128, false>(p, stream);
     return -100;
 }
