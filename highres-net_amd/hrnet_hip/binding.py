@@ -66,6 +66,10 @@ SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_lanczos_kernel": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_lanczos_shift": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "hrn_get_loss": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "hrn_shift_cpsnr_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "hrn_shift_cpsnr": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                   _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_profile_enable": (_c.c_int, [_c.c_int]),
     "hrn_profile_count": (_c.c_int, []),
     "hrn_profile_get": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_int, _c.POINTER(_c.c_long), _c.POINTER(_c.c_double),
@@ -333,4 +337,41 @@ def profile_read():
         n, ms, fl, by = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         _check(lib.hrn_profile_get(i, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)), "hrn_profile_get")
         out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+    return out
+
+
+# --------------------------------------------------------------------------- loss / score reductions
+_METRICS = {"masked_MSE": 0, "cMSE": 1, "cPSNR": 2}
+
+
+def get_loss(srs, hrs, hr_maps, metric="cMSE", crop=0):
+    """get_loss of the reference (train.py:66-87) on device: (B,S,S) tensors -> (B,).  `crop` folds get_crop_mask in."""
+    lib = load_library()
+    if metric not in _METRICS:
+        raise ValueError(f"metric must be one of {sorted(_METRICS)}; got {metric!r}")
+    srs, hrs, hr_maps = _dev_f32(srs, "srs"), _dev_f32(hrs, "hrs"), _dev_f32(hr_maps, "hr_maps")
+    if srs.dim() != 3 or srs.shape != hrs.shape or srs.shape != hr_maps.shape or srs.shape[1] != srs.shape[2]:
+        raise ValueError(f"srs, hrs, hr_maps must be equal (B,S,S) tensors; got {tuple(srs.shape)}, {tuple(hrs.shape)}, {tuple(hr_maps.shape)}")
+    B, S, _ = srs.shape
+    out = torch.empty((B,), dtype=torch.float32, device=srs.device)
+    with torch.cuda.device(srs.device):
+        _check(lib.hrn_get_loss(_ptr(srs), _ptr(hrs), _ptr(hr_maps), B, S, int(crop), _METRICS[metric], _ptr(out), _stream()), "hrn_get_loss")
+    return out
+
+
+def shift_cpsnr(srs, hrs, hr_maps, border_w=3, clip=True):
+    """Batched shift_cPSNR (Evaluator.py:52-73) on device: (B,S,S) tensors -> (B,) best cPSNR over the (2w+1)^2 offsets."""
+    lib = load_library()
+    srs, hrs, hr_maps = _dev_f32(srs, "srs"), _dev_f32(hrs, "hrs"), _dev_f32(hr_maps, "hr_maps")
+    if srs.dim() == 2:
+        srs, hrs, hr_maps = srs[None], hrs[None], hr_maps[None]
+    if srs.dim() != 3 or srs.shape != hrs.shape or srs.shape != hr_maps.shape or srs.shape[1] != srs.shape[2]:
+        raise ValueError("srs, hrs, hr_maps must be equal (B,S,S) tensors")
+    B, S, _ = srs.shape
+    nws = lib.hrn_shift_cpsnr_workspace_bytes(B, int(border_w))
+    out = torch.empty((B,), dtype=torch.float32, device=srs.device)
+    with torch.cuda.device(srs.device):
+        ws = _workspace(nws, srs.device, "shift_cpsnr")
+        _check(lib.hrn_shift_cpsnr(_ptr(srs.contiguous()), _ptr(hrs.contiguous()), _ptr(hr_maps.contiguous()), B, S, int(border_w),
+                                   int(bool(clip)), _ptr(out), _ptr(ws), ws.numel(), _stream()), "hrn_shift_cpsnr")
     return out

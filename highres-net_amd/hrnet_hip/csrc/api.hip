@@ -396,4 +396,26 @@ int hrn_lanczos_shift(const float* img, const float* shift, int b, int c, int H,
     return hrn_launch_lanczos_shift(img, shift, b, c, H, W, out, (hipStream_t)stream);
 }
 
+// ----------------------------------------------------------------- loss / score reductions
+int hrn_get_loss(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out, void* stream) {
+    HRN_CHECK(B > 0 && S > 0 && crop >= 0 && 2 * crop < S, -2, "hrn_get_loss: bad shape B=%d S=%d crop=%d", B, S, crop);
+    HRN_CHECK(metric >= 0 && metric <= 2, -2, "hrn_get_loss: metric must be 0 (masked_MSE), 1 (cMSE) or 2 (cPSNR)");
+    HRN_CHECK(srs && hrs && maps && out, -2, "hrn_get_loss: null argument");
+    return hrn_launch_masked_cmse(srs, hrs, maps, B, S, crop, metric, out, (hipStream_t)stream);
+}
+
+size_t hrn_shift_cpsnr_workspace_bytes(int B, int border) {
+    if (B <= 0 || border < 0) return 0;
+    return (size_t)B * (2 * border + 1) * (2 * border + 1) * sizeof(double);
+}
+
+int hrn_shift_cpsnr(const float* srs, const float* hrs, const float* maps, int B, int S, int border, int clip, float* out,
+                    void* ws, size_t ws_bytes, void* stream) {
+    HRN_CHECK(B > 0 && border >= 0 && S > 2 * border, -2, "hrn_shift_cpsnr: bad shape B=%d S=%d border=%d", B, S, border);
+    HRN_CHECK(B <= 65535, -2, "hrn_shift_cpsnr: batch %d exceeds the grid limit", B);
+    HRN_CHECK(srs && hrs && maps && out && ws, -2, "hrn_shift_cpsnr: null argument");
+    HRN_CHECK(ws_bytes >= hrn_shift_cpsnr_workspace_bytes(B, border), -3, "hrn_shift_cpsnr: workspace too small");
+    return hrn_launch_shift_cpsnr(srs, hrs, maps, B, S, border, clip, (double*)ws, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

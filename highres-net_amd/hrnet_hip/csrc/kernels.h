@@ -21,6 +21,12 @@ int hrn_launch_decoder_pack(int dt, const float* w_iokk, void* packed, hipStream
 int hrn_launch_lanczos_taps(const float* d, int n, float* taps, hipStream_t stream);
 int hrn_launch_lanczos_shift(const float* img, const float* shift, int b, int c, int H, int W, float* out, hipStream_t stream);
 
+// ---- losses.hip
+int hrn_launch_masked_cmse(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out,
+                           hipStream_t stream);
+int hrn_launch_shift_cpsnr(const float* srs, const float* hrs, const float* maps, int B, int S, int border, int clip,
+                           double* scores, float* out, hipStream_t stream);
+
 // ---- shiftnet.hip
 int hrn_launch_bn_stats(const float* x, size_t npix, int C, const float* gamma, const float* beta, float eps,
                         float* scale, float* shift, float* running_mean, float* running_var, float momentum,

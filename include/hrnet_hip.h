@@ -121,6 +121,19 @@ int hrn_lanczos_kernel(const float* dx, int n, float* taps, void* stream);
 /* img (b,c,H,W) f32, shift (c,2) = (dy,dx) per channel -> out (b,c,H,W) f32;  a = 3, N = 7, any p >= 3. */
 int hrn_lanczos_shift(const float* img, const float* shift, int b, int c, int H, int W, float* out, void* stream);
 
+/* ------------------------------------------------------------------ loss / score reductions
+ * hrn_get_loss     <-  get_loss(srs, hrs, hr_maps, metric)   src/train.py:66-87, with get_crop_mask (:90-106) folded in:
+ *                      srs/hrs/hr_maps (B,S,S) f32 -> out (B) f32.  metric: 0 'masked_MSE', 1 'cMSE', 2 'cPSNR' (returns
+ *                      -10 log10(cMSE) exactly like the reference); crop: border width forced to mask 0 (0 = none).
+ * hrn_shift_cpsnr  <-  shift_cPSNR(np.clip(sr,0,1), hr, hr_map, border_w)   src/Evaluator.py:52-73 (cPSNR :11-43),
+ *                      batched: (B,S,S) f32 -> out (B) f32 = max over the (2 border + 1)^2 integer offsets of hr;
+ *                      clip != 0 clamps sr to [0,1] first (predict.py:43, train.py:212); workspace: B*(2b+1)^2 doubles.
+ *                      Status maps are binary (Evaluator's formula squares the mask; identical for 0/1 maps). */
+int hrn_get_loss(const float* srs, const float* hrs, const float* hr_maps, int B, int S, int crop, int metric, float* out, void* stream);
+size_t hrn_shift_cpsnr_workspace_bytes(int B, int border);
+int hrn_shift_cpsnr(const float* srs, const float* hrs, const float* hr_maps, int B, int S, int border, int clip, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ built-in kernel timing (hipEvent pairs)
  * The reference has no profiling hooks; these exist so that bench.py can state, live, the
  * achieved TFLOP/s / GB/s of each kernel family against the gfx950 roofline.  enable(1) clears the table and starts

@@ -1,0 +1,56 @@
+"""GPU (-m gpu): the loss / score reductions behind the hot path, through the C ABI,
+against the values the reference's own `train.get_loss`, `Evaluator.cPSNR` and `Evaluator.shift_cPSNR` produced
+(tests/golden/callers.npz, written by oracle/make_goldens.py) and against the numpy oracle on a full-size batch."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hrnet_np as O
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_get_loss_vs_reference_golden():
+    from hrnet_hip import binding
+    g = util.golden("callers")
+    srs, hrs = util.dev(g["srs"]), util.dev(g["hrs"])
+    mask = g["maps"] * g["crop"][0]                     # train.py:183: torch_mask[0] * hr_maps
+    for metric, key in (("cPSNR", "loss_cpsnr"), ("cMSE", "loss_cmse")):
+        got = binding.get_loss(srs, hrs, util.dev(mask.astype(np.float32)), metric).cpu().numpy()
+        assert util.rel_err(got, g[key]) <= 1e-5
+        # get_crop_mask folded into the kernel: same result from the raw status maps + crop=3
+        got2 = binding.get_loss(srs, hrs, util.dev(g["maps"]), metric, crop=3).cpu().numpy()
+        assert util.rel_err(got2, g[key]) <= 1e-5
+    mm = binding.get_loss(srs, hrs, util.dev(mask.astype(np.float32)), "masked_MSE").cpu().numpy()
+    want = ((mask * g["srs"] - mask * g["hrs"]) ** 2).mean(axis=(1, 2))
+    assert util.rel_err(mm, want) <= 1e-5
+    with pytest.raises(ValueError):
+        binding.get_loss(srs, hrs, util.dev(g["maps"]), "PSNR")
+
+
+def test_shift_cpsnr_vs_reference_golden():
+    from hrnet_hip import binding
+    g = util.golden("callers")
+    got = binding.shift_cpsnr(util.dev(g["srs"]), util.dev(g["hrs"]), util.dev(g["maps"]), border_w=3, clip=True).cpu().numpy()
+    assert util.rel_err(got, g["shift_cpsnr"]) <= 1e-5
+    # border 0 == plain cPSNR of the clipped image
+    got0 = binding.shift_cpsnr(util.dev(g["srs"]), util.dev(g["hrs"]), util.dev(g["maps"]), border_w=0, clip=True).cpu().numpy()
+    assert util.rel_err(got0, g["cpsnr"]) <= 1e-5
+
+
+def test_scores_full_size_vs_oracle():
+    """B=32 frames of 384x384 (the metric's output size): device reductions vs the fp64 numpy oracle."""
+    from hrnet_hip import binding
+    rng = np.random.Generator(np.random.PCG64(4))
+    hr = rng.random((32, 384, 384), dtype=np.float32) * 0.25
+    sr = np.clip(hr + 0.01 * rng.standard_normal(hr.shape).astype(np.float32) + 0.003, 0, 1).astype(np.float32)
+    sr = np.roll(sr, (1, -2), axis=(1, 2))              # a registration error the shift search should undo
+    mp = (rng.random(hr.shape) > 0.05).astype(np.float32)
+    got = binding.shift_cpsnr(util.dev(sr), util.dev(hr), util.dev(mp)).cpu().numpy()
+    want = O.shift_cpsnr(sr.astype(np.float64), hr.astype(np.float64), mp.astype(np.float64))
+    assert util.rel_err(got, want) <= 1e-5
+    plain = binding.shift_cpsnr(util.dev(sr), util.dev(hr), util.dev(mp), border_w=0).cpu().numpy()
+    assert (got > plain + 3.0).all()                    # the best shift beats the unregistered score by a wide margin
+    loss = binding.get_loss(util.dev(sr), util.dev(hr), util.dev(mp), "cPSNR").cpu().numpy()
+    assert util.rel_err(loss, O.get_loss(sr, hr, mp, "cPSNR")) <= 1e-5
