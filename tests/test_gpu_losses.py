@@ -54,3 +54,21 @@ def test_scores_full_size_vs_oracle():
     assert (got > plain + 3.0).all()                    # the best shift beats the unregistered score by a wide margin
     loss = binding.get_loss(util.dev(sr), util.dev(hr), util.dev(mp), "cPSNR").cpu().numpy()
     assert util.rel_err(loss, O.get_loss(sr, hr, mp, "cPSNR")) <= 1e-5
+
+
+def test_hrnet_large_tiles_512():
+    """BASELINE config 5 geometry (512x512 -> 1536x1536 tiles; small batch here): the persistent tile walk, halo logic
+    and the staging buffers at 16x the pixels per image.  Properties: determinism, batch independence, and agreement of
+    the bf16 path with the exact-fp32 path within the bf16 tolerance."""
+    from oracle import synth
+    lrs, alphas = synth.fast_batch(11, 2, 6, 512)
+    x, a = util.dev(lrs), util.dev(alphas)
+    m16, m32 = util.hip_hrnet("bf16"), util.hip_hrnet("fp32")
+    with torch.no_grad():
+        y = m16(x, a).clone()
+        assert y.shape == (2, 1, 1536, 1536) and torch.isfinite(y).all()
+        assert torch.equal(m16(x, a), y)
+        assert torch.equal(m16(x[1:2].contiguous(), a[1:2].contiguous())[0], y[1])
+        ref = m32(x, a)
+    assert util.rel_err(y.cpu().numpy(), ref.cpu().numpy()) <= 4e-2
+    assert util.psnr_db(y.cpu().numpy(), ref.cpu().numpy()) >= 42.0
