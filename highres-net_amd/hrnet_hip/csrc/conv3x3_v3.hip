@@ -22,11 +22,13 @@
 // Hand-offs are raw s_barrier (no compiler fence draining loads in flight), one per weight stage:
 //   COUT = 64 : stage = 3 taps (48 MFMA per compute wave between barriers), COUT = 128: stage = 1 tap (32 MFMA).
 // LDS: 2 input halo tiles [10][34] px x 144 B, 2 weight stages, bias = 153.5 KB (COUT 64) / 135.3 KB (COUT 128).
-// Known cost left on the table (r01 ablation, profiles/r01_v3_ablation.txt): the epilogue runs on the lone compute wave of
-// each SIMD with the MFMA pipe idle (+0.4 / +0.75 / +0.23 ms per 128x128 / 64x64 / 128x64 launch at c3), and the
-// per-tile weight re-staging keeps the LDS 60-90 % busy.  Two attempts to hand the epilogue to the memory waves (whole
-// tile after the hand-off barrier; 16-piece residual ring spread over the stages) were correct but slower - a late
-// memory wave stalls the stage barrier for everybody - and are not kept.
+// Known cost left on the table (r01 ablations, profiles/r01_v3_*.txt): an epilogue run by the lone compute wave of each
+// SIMD leaves the MFMA pipe idle (+0.4 / +0.75 / +0.23 ms per 128x128 / 64x64 / 128x64 launch at c3), and the per-tile
+// weight re-staging keeps the LDS 60-90 % busy (compute waves alone: 0.53 ms, with the loaders: 0.79 ms for 128x128).
+// The OFFLOAD variants below move the stores to the INPUT waves (they gain 2-8 %); variants in which a memory wave also
+// had to LOAD for the epilogue (residual at store time, or a 16-piece residual ring), a tile-level software pipeline
+// with two accumulator sets, and delaying the loaders' LDS writes (s_sleep) were all correct but not faster - any
+// wave that is late for a stage barrier stalls everybody - and are not kept.
 #include "conv3x3.h"
 #include <stdlib.h>
 
