@@ -39,8 +39,13 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(unsigned short, h);
 }
+// two floats -> one dword of two bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32.  (Converting the halves separately and
+// or-ing them costs four instructions; the epilogues do this for every output pair.)
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
-    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <int DT> struct ElemOf;

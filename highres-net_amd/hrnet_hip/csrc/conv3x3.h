@@ -32,5 +32,8 @@ static inline size_t conv_packed_elems(int cin, int cout) { return (size_t)cin *
 // Launch on `stream`.  dt: HRN_F32 / HRN_BF16; (cin, cout) in {64,128}^2.  Returns 0 or a negative error.
 int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream_t stream);
 
+// bf16 64 -> 64 with LDS-resident weights (conv3x3_r64.hip); -100 = not applicable, caller picks another kernel.
+int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream);
+
 // Pack OIHW f32 weights [cout][cin][3][3] into the kernel's step-major layout (device to device).
 int hrn_launch_conv_pack(int dt, int cin, int cout, const float* w_oihw, void* packed, hipStream_t stream);

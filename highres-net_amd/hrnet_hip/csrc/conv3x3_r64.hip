@@ -1,0 +1,351 @@
+// conv3x3 64 -> 64, bf16, RESIDENT weights + two ping-pong wave teams: the encoder's five 64->64 layers
+// (HRNet.py:17-22, :55-60).
+//
+// Why a third kernel: 64->64 sits at the MFMA/HBM ridge (288 FLOP/B), and in conv3x3_v3 its time was neither: every
+// 256-pixel tile re-staged all 72 KB of weights through the slow ds_write path (a barrier per 3 taps), and the epilogue
+// (bias, PReLU, residual, rounding: ~2,000 VALU cycles per tile) ran while the matrix pipe idled.  For CIN = COUT = 64
+// the whole weight tensor fits in LDS for the lifetime of a persistent workgroup, next to TWO halo tiles:
+//     weights  9 x 64 x 128 B            73,728 B   16-byte chunks XOR-swizzled by (row >> 1) & 7: conflict-free b128 reads
+//     input    2 x [10][34] px x 128 B   87,040 B   one halo tile per team, chunks swizzled by (pixel >> 1) & 7
+//     bias                                   256 B                                        = 161,024 B
+// 512 threads = two teams of four waves, one wave of each team on every SIMD.  The teams alternate:
+//     ON  phase: 36 k-steps (9 taps x 4) on the team's halo tile - one uninterrupted hand-pipelined ds_read/MFMA stream,
+//                no weight traffic, no address arithmetic beyond one v_xor per fragment, no barrier inside;
+//     OFF phase: fetch the team's next halo tile HBM -> VGPR, finish the tile just multiplied straight from the
+//                accumulators (bias, PReLU, v_permlane32_swap so every lane owns 64 contiguous bytes of one pixel,
+//                residual, one bf16 rounding, 16-byte stores), commit the fetched tile into the team's LDS buffer.
+// One workgroup barrier per phase.  While team A's waves occupy the matrix pipe, team B's waves on the same SIMDs do the
+// VALU / VMEM / ds_write work, so neither the epilogue nor the input staging costs MFMA time.
+// Same math / layouts / packed weights / persistent XCD-windowed tile walk as the other conv kernels.
+#include <type_traits>
+#include "conv3x3.h"
+
+namespace {
+
+constexpr int HALO_H = CONV_TILE_H + 2;
+constexpr int HALO_W = CONV_TILE_W + 2;
+constexpr int IN_BYTES = HALO_H * HALO_W * 128;              // 43,520 (unpadded, swizzled)
+constexpr int N_IN_PIECES = HALO_H * HALO_W * 8;             // 2,720
+constexpr int W_BYTES = 9 * 64 * 128;                        // 73,728
+constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + 256;
+constexpr int TEAM = 256;                                    // threads per team
+constexpr int PI = (N_IN_PIECES + TEAM - 1) / TEAM;          // 11 halo pieces per thread
+
+__device__ __forceinline__ void lds_done_then_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// v_max_f32 without the canonicalising v_max(x, x) the compiler puts in front of fmaxf (both operands NaN -> NaN, so
+// PReLU still propagates NaNs)
+__device__ __forceinline__ float raw_max(float a, float b) {
+    float y;
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+
+template <bool RES>
+__global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* w_lds = smem;
+    float* bias_lds = (float*)(smem + W_BYTES + 2 * IN_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, tw = wave & 3, tt = tid & (TEAM - 1);
+    unsigned char* in_lds = smem + W_BYTES + team * IN_BYTES;
+    const int r = lane & 31, hh = lane >> 5;
+    const int H = p.H, W = p.W;
+    const size_t hw = (size_t)H * W;
+    const unsigned tiles_x = (W + CONV_TILE_W - 1) / CONV_TILE_W;
+    const unsigned tiles_y = (H + CONV_TILE_H - 1) / CONV_TILE_H;
+    const unsigned tiles = tiles_x * tiles_y;
+    const unsigned total = tiles * (unsigned)p.M;           // < 2^31 (checked by the launcher)
+    const unsigned G = gridDim.x;
+    const unsigned bid = blockIdx.x;
+    const unsigned slot = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+    if (slot >= total) return;
+    const int ntl = (int)((total - slot + G - 1) / G);      // tiles of this workgroup; team T takes local tiles T, T+2, ...
+    const int nmine = (ntl + 1 - team) >> 1;
+
+    // this team's tile cursor (image, tile in image): tiles slot + (2k + team) * G, advanced without divisions
+    unsigned cur_m = (slot + team * G) / tiles, cur_t = (slot + team * G) - cur_m * tiles;
+    const unsigned step_m = (2 * G) / tiles, step_t = 2 * G - step_m * tiles;
+
+    // ---- one-time: all nine weight slices -> LDS (chunk c of row `row` lives at chunk c ^ ((row >> 1) & 7)), bias
+    {
+        const u32x4* wg = (const u32x4*)p.wpk;                  // [tap][64 rows][8 chunks]
+#pragma unroll
+        for (int j = 0; j < W_BYTES / 16 / 512; ++j) {
+            const int idx = tid + j * 512;
+            const int row = idx >> 3, c = idx & 7;              // row = tap*64 + cout
+            *(u32x4*)(w_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = wg[idx];
+        }
+        if (tid < 64) bias_lds[tid] = p.bias[tid];
+    }
+
+    // ---- halo tile: HBM -> VGPR (issue) and VGPR -> this team's LDS buffer (commit)
+    // Piece map of a team thread tq (16-byte piece `part` = tq & 7 of one halo pixel), chosen so that no division is
+    // needed and the row test is wave-uniform:
+    //     pieces 0..9 : halo row it, halo column tq >> 3 (0..31)
+    //     piece  10   : threads tq < 160 only: halo row tq >> 4, halo column 32 + ((tq >> 3) & 1)
+    // The geometry is recomputed from an opaque copy of the thread index: left to itself the compiler keeps 40+
+    // loop-invariant registers of it alive through the MFMA phase and spills.
+    u32x4 reg[PI];
+    unsigned okmask = 0;                                    // bit it: piece `it` lies inside the image
+    bool edge = false;                                      // the fetched tile has out-of-image halo pixels (uniform)
+    auto issue = [&](unsigned m, unsigned t) __attribute__((always_inline)) {
+        const int ty = t / tiles_x;
+        const int y0 = ty * CONV_TILE_H, x0 = (t - ty * tiles_x) * CONV_TILE_W;
+        const unsigned char* base = (const unsigned char*)p.in + (size_t)m * hw * 128;     // uniform: image base
+        edge = y0 < 1 || y0 + CONV_TILE_H + 1 > H || x0 < 1 || x0 + CONV_TILE_W + 1 > W;
+        int tq = tt;
+        asm volatile("" : "+v"(tq));
+        const int part = tq & 7, cg = tq >> 3;
+        const int gx = x0 - 1 + cg;
+        const bool xok = (unsigned)gx < (unsigned)W;
+        const int off0 = ((y0 - 1) * W + gx) * 128 + part * 16;
+        unsigned okm = 0;
+#pragma unroll
+        for (int it = 0; it < PI - 1; ++it) {
+            const bool ok = xok && (unsigned)(y0 - 1 + it) < (unsigned)H;
+            // branch-free: out-of-image pieces read byte 0 of the image and are zeroed at commit time
+            reg[it] = *(const u32x4*)(base + (ok ? (unsigned)(off0 + it * W * 128) : 0u));
+            okm |= (unsigned)ok << it;
+        }
+        {
+            const int gy2 = y0 - 1 + (tq >> 4), gx2 = x0 + 31 + (cg & 1);
+            const bool ok = tq < 160 && (unsigned)gy2 < (unsigned)H && (unsigned)gx2 < (unsigned)W;
+            reg[PI - 1] = *(const u32x4*)(base + (ok ? (unsigned)((gy2 * W + gx2) * 128 + part * 16) : 0u));
+            okm |= (unsigned)ok << (PI - 1);
+        }
+        okmask = okm;
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+        int tq = tt;
+        asm volatile("" : "+v"(tq));
+        const int part = tq & 7, cg = tq >> 3;
+        if (edge) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int it = 0; it < PI; ++it) reg[it] = (okmask >> it) & 1u ? reg[it] : z;
+        }
+#pragma unroll
+        for (int it = 0; it < PI - 1; ++it) {
+            const int pix = it * HALO_W + cg;
+            *(u32x4*)(in_lds + pix * 128 + ((part ^ ((pix >> 1) & 7)) << 4)) = reg[it];
+        }
+        if (tq < 160) {
+            const int pix = (tq >> 4) * HALO_W + 32 + (cg & 1);
+            *(u32x4*)(in_lds + pix * 128 + ((part ^ ((pix >> 1) & 7)) << 4)) = reg[PI - 1];
+        }
+    };
+
+    const bool has_slope = p.slope != nullptr;
+    const float slope = has_slope ? p.slope[0] : 0.f;
+    const bool slope01 = slope >= 0.f && slope <= 1.f;
+    // fragment addresses.  Weights: row r of cout block cb, k-step ks -> a_off[ks] + cb*4096 + tap*8192.
+    // Input: halo pixel (2*tw + pb + ky, r + kx), k-step ks -> b_off[pb + ky][kx] ^ (ks << 5)   (12 registers, not 72;
+    // the buffer base has zero low bits, so it is folded in before the xor)
+    unsigned a_off[4], b_off[4][3];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a_off[ks] = r * 128 + (((ks * 2 + hh) ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+    for (int row = 0; row < 4; ++row)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pix = (2 * tw + row) * HALO_W + r + kx;
+            b_off[row][kx] = (unsigned)(W_BYTES + team * IN_BYTES) + (((unsigned)pix << 7) | ((unsigned)(((pix >> 1) & 7) ^ hh) << 4));
+        }
+
+    const unsigned lane_off = (unsigned)((2 * tw * W + r) * 128 + hh * 64);
+    f32x16 acc[2][2];                                       // [cout block][pixel row]; lives from the ON phase into the OFF phase
+
+    // ---- ON phase: the 36 k-steps of one tile
+    auto multiply = [&]() __attribute__((always_inline)) {
+        // the accumulators start at the bias (element 4g + j of block cb = channel cb*32 + 8g + 4hh + j)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *(const f32x4*)(bias_lds + cb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[cb][0][4 * g + j] = b[j]; acc[cb][1][4 * g + j] = b[j]; }
+            }
+        constexpr int NK = 36, DEPTH = 2;
+        bf16x8 fa[DEPTH + 1][2], fb[DEPTH + 1][2];
+        auto load_k = [&](int i, int s_) __attribute__((always_inline)) {
+            const int tap = i >> 2, ks = i & 3;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned char* wb = w_lds + tap * 8192 + a_off[ks];
+            fa[s_][0] = *(const bf16x8*)(wb);
+            fa[s_][1] = *(const bf16x8*)(wb + 4096);
+            unsigned kbits = 0;
+            if (ks) asm volatile("s_mov_b32 %0, %1" : "=s"(kbits) : "n"(ks << 5));     // opaque: keeps the compiler from
+#pragma unroll                                                                          // materialising all 72 addresses
+            for (int pb = 0; pb < 2; ++pb) fb[s_][pb] = *(const bf16x8*)(smem + (b_off[pb + ky][kx] ^ kbits));
+        };
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) load_k(i, i);
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            if (i + DEPTH < NK) load_k(i + DEPTH, (i + DEPTH) % (DEPTH + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % (DEPTH + 1)][cb], fb[i % (DEPTH + 1)][0], acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % (DEPTH + 1)][cb], fb[i % (DEPTH + 1)][1], acc[cb][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- residual of the tile at the cursor: the 64 bytes this lane will own after the swap (channels 32*hh .. 32*hh+31
+    // of its pixel).  Fetched at the START of the ON phase, consumed in the OFF phase - a whole K loop of latency cover.
+    u32x4 resv[2][4];
+    auto fetch_residual = [&]() __attribute__((always_inline)) {
+        const int m = (int)cur_m;
+        const int ty = cur_t / tiles_x;
+        const int y0 = ty * CONV_TILE_H, x0 = (cur_t - ty * tiles_x) * CONV_TILE_W;
+        const unsigned char* rbase = (const unsigned char*)p.res + (size_t)m * hw * 128;               // res_mode 1 (image base)
+        if (p.res_mode == 3) {
+            const int ob = m / p.out_h, oi = m - ob * p.out_h;
+            rbase = (const unsigned char*)p.res + ((size_t)ob * p.res_vs + oi) * hw * 128;
+        }
+        const int gx = x0 + r, gxc = gx < W ? gx : W - 1;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int gy = y0 + 2 * tw + pb, gyc = gy < H ? gy : H - 1;
+            const u32x4* rp = (const u32x4*)(rbase + (unsigned)((gyc * W + gxc) * 128 + hh * 64));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) resv[pb][g] = rp[g];
+        }
+    };
+
+    // ---- OFF phase: finish the tile at the cursor from the accumulators, refill the team's halo buffer with the next one
+    auto finish = [&](bool more) __attribute__((always_inline)) {
+        const int m = (int)cur_m;
+        const int ty = cur_t / tiles_x;
+        const int y0 = ty * CONV_TILE_H, x0 = (cur_t - ty * tiles_x) * CONV_TILE_W;
+        cur_t += step_t; cur_m += step_m;
+        if (cur_t >= tiles) { cur_t -= tiles; ++cur_m; }
+        size_t oimg = (size_t)m;
+        int ob = 0, oi = 0;
+        if (p.out_h > 0) { ob = m / p.out_h; oi = m - ob * p.out_h; oimg = (size_t)ob * p.out_vs + oi; }
+        // uniform base at the tile origin; per-lane byte offset of (row 2*tw, column r, channel half hh) is tile-independent
+        unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * 128;
+        const int gx = x0 + r;
+        float res_alpha = 1.f;
+        if (RES && p.res_mode == 3 && p.alphas) res_alpha = p.alphas[(size_t)ob * p.alpha_vs + (p.pair_last - oi)];
+        if (more) issue(cur_m, cur_t);                      // in flight while the epilogue runs
+        // ACT 0: no activation | 1: PReLU with 0 <= slope <= 1 as max(x, slope*x) (2 VALU) | 2: general PReLU (3 VALU)
+        auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int gy = y0 + 2 * tw + pb;
+            u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * 128) + lane_off);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float xa[4], xb[4];                         // channels 8g + 4hh + j of cout block 0 / block 1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xa[j] = acc[0][pb][4 * g + j]; xb[j] = acc[1][pb][4 * g + j]; }
+                if (ACT == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xa[j] = raw_max(xa[j], slope * xa[j]); xb[j] = raw_max(xb[j], slope * xb[j]); }
+                } else if (ACT == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xa[j] = xa[j] >= 0.f ? xa[j] : slope * xa[j]; xb[j] = xb[j] >= 0.f ? xb[j] : slope * xb[j]; }
+                }
+                // v_permlane32_swap(a, b): lanes 32..63 of a <-> lanes 0..31 of b.  Afterwards a lane holds, for its pixel,
+                // (a, b) = channels 32*hh + 8g + (0..3, 4..7): 16 contiguous bytes once rounded to bf16.
+                u32x4 u;
+                if (RES) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa[j]), __float_as_uint(xb[j]), false, false);
+                        v[j] = __uint_as_float(sw[0]);
+                        v[4 + j] = __uint_as_float(sw[1]);
+                    }
+                    const u32x4 rq = resv[pb][g];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float r0 = __uint_as_float(rq[j] << 16), r1 = __uint_as_float(rq[j] & 0xffff0000u);
+                        if (p.res_mode == 3) { v[2 * j] = r0 + res_alpha * v[2 * j]; v[2 * j + 1] = r1 + res_alpha * v[2 * j + 1]; }
+                        else { v[2 * j] += r0; v[2 * j + 1] += r1; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
+                } else {                                    // no residual: round first, swap packed pairs (half the swaps)
+                    const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pack2_bf16(xa[0], xa[1]), pack2_bf16(xb[0], xb[1]), false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pack2_bf16(xa[2], xa[3]), pack2_bf16(xb[2], xb[3]), false, false);
+                    u[0] = s0[0]; u[1] = s1[0]; u[2] = s0[1]; u[3] = s1[1];
+                }
+                if (gy < H && gx < W) op[g] = u;
+            }
+        }
+        };
+        if (!has_slope) epilogue(std::integral_constant<int, 0>{});
+        else if (slope01) epilogue(std::integral_constant<int, 1>{});
+        else epilogue(std::integral_constant<int, 2>{});
+        if (more) commit();
+    };
+
+    if (nmine > 0) { issue(cur_m, cur_t); commit(); }
+    lds_done_then_barrier();                                // weights, bias, both teams' first halo tiles
+
+    // phase ph: team 0 is at step q = ph, team 1 at q = ph - 1; even q = ON (tile q/2), odd q = OFF (tile (q-1)/2)
+    for (int ph = 0; ph <= ntl; ++ph) {
+        const int q = ph - team;
+        if (q >= 0) {
+            const int k = q >> 1;
+            if (k < nmine) {
+                if ((q & 1) == 0) { if (RES) fetch_residual(); multiply(); }
+                else finish(k + 1 < nmine);
+            }
+        }
+        if (ph < ntl) lds_done_then_barrier();
+    }
+}
+
+int g_r64_cus = 0;
+
+template <bool RES>
+int launch_r64(const ConvParams& p, long grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HRN_HIP(hipFuncSetAttribute((const void*)conv3x3_r64_kernel<RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_r64_kernel<RES>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// bf16 64 -> 64 with a plain input tensor (no pair gather).  Returns -100 when not applicable.
+int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream) {
+    if (p.scale || p.relu || p.in_pair || p.res_mode == 2) return -100;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    if (g_r64_cus == 0) {
+        int dev = 0, n = 0;
+        HRN_HIP(hipGetDevice(&dev));
+        HRN_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        g_r64_cus = n > 0 ? n : 256;
+    }
+    const long tiles = (long)((p.W + CONV_TILE_W - 1) / CONV_TILE_W) * ((p.H + CONV_TILE_H - 1) / CONV_TILE_H);
+    const long total = tiles * p.M;
+    HRN_CHECK(total > 0, -2, "conv3x3_r64: bad tile count %ld", total);
+    if (total >= (1L << 30) || (long)p.H * p.W * 128 >= (1L << 31)) return -100;     // 32-bit tile / in-image byte arithmetic
+    long grid = g_r64_cus;
+    if (total < grid) grid = total;
+    if (grid >= 8) grid &= ~7L;
+    const double px = (double)p.M * p.H * p.W;
+    HrnProfScope prof(p.res_mode ? "conv3x3_bf16_64x64+res" : "conv3x3_bf16_64x64", 2.0 * 64 * 64 * 9 * px,
+                      px * 2 * (64 + 64 + (p.res_mode ? 64 : 0)), stream);
+    return p.res_mode ? launch_r64<true>(p, grid, stream) : launch_r64<false>(p, grid, stream);
+}

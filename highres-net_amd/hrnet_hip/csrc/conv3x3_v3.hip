@@ -511,7 +511,13 @@ int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t st
     // the kernel supports them (every COUT = 64 layer; COUT = 128 layers without a residual)
     static int offload = -1;
     if (offload < 0) { const char* e = getenv("HRN_CONV_OFFLOAD"); offload = e ? atoi(e) : 1; }
-    if (cin == 64 && cout == 64) return offload ? launch_v3<64, 64, true>(p, stream) : launch_v3<64, 64, false>(p, stream);
+    if (cin == 64 && cout == 64) {
+        // resident-weights kernel (conv3x3_r64.hip) for the encoder's plain 64 -> 64 layers; HRN_CONV_R64=0 for A/B timing
+        static int r64 = -1;
+        if (r64 < 0) { const char* e = getenv("HRN_CONV_R64"); r64 = e ? atoi(e) : 1; }
+        if (r64) { const int rc = hrn_launch_conv3x3_r64(p, stream); if (rc != -100) return rc; }
+        return offload ? launch_v3<64, 64, true>(p, stream) : launch_v3<64, 64, false>(p, stream);
+    }
     if (cin == 128 && cout == 64) return offload ? launch_v3<128, 64, true>(p, stream) : launch_v3<128, 64, false>(p, stream);
     if (cin == 128 && cout == 128)
         return (offload && p.res_mode == 0) ? launch_v3<128, 128, true>(p, stream) : launch_v3<128, 128, false>(p, stream);
