@@ -519,6 +519,12 @@ int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t st
         return offload ? launch_v3<64, 64, true>(p, stream) : launch_v3<64, 64, false>(p, stream);
     }
     if (cin == 128 && cout == 64) return offload ? launch_v3<128, 64, true>(p, stream) : launch_v3<128, 64, false>(p, stream);
+    if (cin == 128 && cout == 128) {
+        // 512-pixel-tile, 8-MFMA-wave, LDS-DMA kernel (conv3x3_v4.hip); HRN_CONV_V4=0 for A/B timing
+        static int v4 = -1;
+        if (v4 < 0) { const char* e = getenv("HRN_CONV_V4"); v4 = e ? atoi(e) : 1; }
+        if (v4) { const int rc = hrn_launch_conv3x3_v4(p, stream); if (rc != -100) return rc; }
+    }
     if (cin == 128 && cout == 128)
         return (offload && p.res_mode == 0) ? launch_v3<128, 128, true>(p, stream) : launch_v3<128, 128, false>(p, stream);
     return -100;

@@ -1,0 +1,333 @@
+// conv3x3 128 -> 128, bf16: the fusion residual block's two big layers (HRNet.py:90-95, :123-127) - 47 % of the forward FLOPs.
+//
+// conv3x3_v3 runs these with one MFMA wave per SIMD plus four loader waves that carry every byte HBM/L2 -> VGPR -> LDS;
+// measured there: matrix pipe ~47 % busy, 440 vector-memory instructions and 380 KB of ds_write per 256-pixel tile, the
+// epilogue exposed.  This kernel is built the other way round, after the shape the CDNA4 guide measures fastest for
+// GEMM-like loops (8 waves, two per SIMD, LDS-DMA staging, counted vmcnt, raw barriers):
+//   * 512 output pixels (16 x 32) per tile: the 288 KB of weights stream through LDS once per 512 pixels, not per 256;
+//   * 8 MFMA waves, two per SIMD; wave w owns pixel rows 2w, 2w+1 x all 128 output channels (128 accumulator registers):
+//     6 fragment reads per 8 MFMAs, and each SIMD always has a second wave to issue from while one waits on LDS;
+//   * all staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no loader waves.  The LDS
+//     images are lane-linear, so the bank swizzle is applied to each lane's SOURCE address and again on the ds_read;
+//   * K is walked as 4 chunks of 32 input channels (64 B per pixel) x 3 tap rows: one stage = 3 taps x 32 channels
+//     = 24 KB of weights (ring of 3) against a double-buffered 18 x 34-pixel halo chunk (39 KB each); 48 MFMAs per wave
+//     and ONE barrier per stage; stage s+2's weights and the next chunk's halo are in flight while stage s multiplies;
+//   * epilogue from the accumulators (bias pre-loaded into them, PReLU, v_permlane32_swap -> 64 contiguous bytes per lane,
+//     residual, one bf16 rounding, 16-byte stores).
+// LDS: 3 x 24,576 (weights) + 2 x 39,936 (halo) + 512 (bias) = 154,112 B.
+// Ordering rules followed (guide, "Pipelining across barriers"): a wave waits for its own DMAs with a counted vmcnt
+// BEFORE the barrier that precedes the stage reading them; a buffer is re-filled only after a barrier that every reader
+// of its previous contents has passed.
+#include <type_traits>
+#include "conv3x3.h"
+
+namespace {
+
+constexpr int T4_H = 16, T4_W = 32;
+constexpr int HW4 = T4_W + 2;                             // halo width 34
+constexpr int NPIX = (T4_H + 2) * HW4;                    // 612 halo pixels
+constexpr int N_IN_DMA = (NPIX * 64 + 1023) / 1024;       // 39 wave-instructions of 1 KB per halo chunk
+constexpr int IN_BYTES = N_IN_DMA * 1024;                 // 39,936
+constexpr int WST_BYTES = 3 * 128 * 64;                   // 24,576: 3 taps x 128 couts x 32 cin
+constexpr int OFF_IN = 3 * WST_BYTES;
+constexpr int OFF_BIAS = OFF_IN + 2 * IN_BYTES;
+constexpr int LDS_BYTES = OFF_BIAS + 512;
+
+__device__ __attribute__((aligned(16))) unsigned hrn_v4_zero16[4];     // source of out-of-image halo pixels
+
+__device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ float raw_max4(float a, float b) {
+    float y;
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+__device__ __forceinline__ void wait_vm(int n) {          // counted wait; n is wave-uniform and one of the values below
+    if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void lds_done_then_barrier4() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <bool RES>
+__global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bias_lds = (float*)(smem + OFF_BIAS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int H = p.H, W = p.W;
+    const size_t hw = (size_t)H * W;
+    const unsigned tiles_x = (W + T4_W - 1) / T4_W;
+    const unsigned tiles_y = (H + T4_H - 1) / T4_H;
+    const unsigned tiles = tiles_x * tiles_y;
+    const unsigned total = tiles * (unsigned)p.M;
+    const unsigned G = gridDim.x;
+    const unsigned bid = blockIdx.x;
+    const unsigned slot = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+    if (slot >= total) return;
+    const int ntl = (int)((total - slot + G - 1) / G);
+    unsigned cur_m = slot / tiles, cur_t = slot - cur_m * tiles;            // tile being multiplied
+    const unsigned step_m = G / tiles, step_t = G - step_m * tiles;
+    const bool in_pair = p.in_pair != 0;
+
+    // view (image) base of input chunk c (32 channels = 64 B) of image m, and the pixel pitch there
+    auto chunk_src = [&](unsigned m, int c, int& pitch) __attribute__((always_inline)) -> const unsigned char* {
+        if (in_pair) {
+            const int b = m / p.pair_h, i = m - b * p.pair_h;
+            const int v = c < 2 ? i : p.pair_last - i;
+            pitch = 128;
+            return (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + v) * hw * 128 + (c & 1) * 64;
+        }
+        pitch = 256;
+        return (const unsigned char*)p.in + (size_t)m * hw * 256 + c * 64;
+    };
+
+    // ---- LDS-DMA issue: halo chunk c of tile (m, t) -> input buffer `buf`.  Wave w issues pieces j = w, w+8, ... < 39;
+    // piece j, lane i -> LDS bytes j*1024 + i*16 = halo pixel j*16 + (i >> 2), physical 16-B chunk i & 3, which holds
+    // logical chunk (i & 3) ^ ((pixel >> 2) & 3).  Returns the number of DMAs this wave issued.
+    const int n_in = w < (N_IN_DMA & 7) ? (N_IN_DMA >> 3) + 1 : (N_IN_DMA >> 3);
+    auto issue_in = [&](unsigned m, unsigned t, int c, int buf) __attribute__((always_inline)) {
+        const int ty = t / tiles_x;
+        const int y0 = ty * T4_H, x0 = (t - ty * tiles_x) * T4_W;
+        int pitch;
+        const unsigned char* base = chunk_src(m, c, pitch);
+        int lq = lane;
+        asm volatile("" : "+v"(lq));                        // keep the per-piece geometry out of long-lived registers
+#pragma unroll
+        for (int jj = 0; jj < (N_IN_DMA + 7) / 8; ++jj) {
+            const int j = w + 8 * jj;
+            if (j < N_IN_DMA) {
+                const int pix = j * 16 + (lq >> 2);
+                const int lc = (lq & 3) ^ ((pix >> 2) & 3);
+                const int py = pix / HW4, px = pix - py * HW4;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                const bool ok = pix < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const unsigned char* src = ok ? base + ((size_t)(gy * W + gx) * pitch + lc * 16) : (const unsigned char*)hrn_v4_zero16;
+                dma16(src, smem + OFF_IN + buf * IN_BYTES + j * 1024);
+            }
+        }
+    };
+    // ---- LDS-DMA issue: weights of stage (chunk c, tap row tg) -> ring slot.  Wave w fetches couts 16w..16w+15 of each of
+    // the three taps (3 DMAs): lane i -> cout 16w + (i >> 2), physical chunk i & 3 = logical (i & 3) ^ ((cout >> 2) & 3).
+    const unsigned w_lane_off = (unsigned)((16 * w + (lane >> 2)) * 128 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    auto issue_w = [&](int c, int tg, int slot_) __attribute__((always_inline)) {
+        const unsigned char* base = (const unsigned char*)p.wpk + (size_t)((c >> 1) * 9 + tg * 3) * 16384 + (c & 1) * 64 + w_lane_off;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) dma16(base + kx * 16384, smem + slot_ * WST_BYTES + kx * 8192 + w * 1024);
+    };
+
+    const bool has_slope = p.slope != nullptr;
+    const float slope = has_slope ? p.slope[0] : 0.f;
+    const bool slope01 = slope >= 0.f && slope <= 1.f;
+
+    // fragment addresses.  Weights: cout row cb*32 + r, k-step ks -> a_off[ks] + cb*2048 + kx*8192 + slot*24576.
+    // Input: halo pixel (2w + pb + tg, r + kx) -> b_off[pb + tg][kx] ^ (ks << 5) + buffer base (low bits zero).
+    unsigned a_off[2], b_off[4][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_off[ks] = (unsigned)(r * 64 + (((ks * 2 + hh) ^ ((r >> 2) & 3)) << 4));
+#pragma unroll
+    for (int row = 0; row < 4; ++row)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pix = (2 * w + row) * HW4 + r + kx;
+            b_off[row][kx] = (unsigned)(OFF_IN + pix * 64 + (((hh) ^ ((pix >> 2) & 3)) << 4));
+        }
+    const unsigned lane_out = (unsigned)((2 * w * W + r) * 256 + hh * 64);     // byte offset of (row 2w, col r, half hh) in a tile
+
+    f32x16 acc[4][2];                                       // [cout block][pixel row]
+
+    if (tid < 128) bias_lds[tid] = p.bias[tid];
+    // prologue: weights of stages 0 and 1, halo chunk 0 of the first tile
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    issue_in(cur_m, cur_t, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_done_then_barrier4();
+
+    for (int tl = 0; tl < ntl; ++tl) {
+        const bool more_tiles = tl + 1 < ntl;
+        unsigned nxt_t = cur_t + step_t, nxt_m = cur_m + step_m;
+        if (nxt_t >= tiles) { nxt_t -= tiles; ++nxt_m; }
+
+        // the accumulators start at the bias (element 4g + j of block cb = channel cb*32 + 8g + 4hh + j)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *(const f32x4*)(bias_lds + cb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[cb][0][4 * g + j] = b[j]; acc[cb][1][4 * g + j] = b[j]; }
+            }
+
+        for (int c = 0; c < 4; ++c) {
+            const unsigned inbase = (unsigned)((c & 1) * IN_BYTES);
+#pragma unroll
+            for (int tg = 0; tg < 3; ++tg) {
+                // ---- in flight during this stage: weights of stage s+2 (ring slot (tg+2)%3), and at tg == 0 the next halo chunk
+                {
+                    const int tg2 = (tg + 2) % 3, c2 = (c + (tg + 2) / 3) & 3;
+                    issue_w(c2, tg2, tg2);
+                }
+                int issued = 3;
+                if (tg == 0) {
+                    if (c < 3) { issue_in(cur_m, cur_t, c + 1, (c + 1) & 1); issued += n_in; }
+                    else if (more_tiles) { issue_in(nxt_m, nxt_t, 0, 0); issued += n_in; }
+                }
+                // ---- 3 taps x 2 k-steps, fragment reads one step ahead of their MFMAs
+                bf16x8 fa[2][4], fb[2][2];
+                auto load_step = [&](int i, int s_) __attribute__((always_inline)) {
+                    const int kx = i >> 1, ks = i & 1;
+                    const unsigned char* wb = smem + tg * WST_BYTES + kx * 8192 + a_off[ks];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) fa[s_][cb] = *(const bf16x8*)(wb + cb * 2048);
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+                        fb[s_][pb] = *(const bf16x8*)(smem + ((b_off[pb + tg][kx] + inbase) ^ (unsigned)(ks << 5)));
+                };
+                load_step(0, 0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (i + 1 < 6) load_step(i + 1, (i + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][cb], fb[i & 1][0], acc[cb][0], 0, 0, 0);
+                        acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][cb], fb[i & 1][1], acc[cb][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // everything issued before this stage has landed once only this stage's DMAs are outstanding:
+                // stage s+1's weights (issued in stage s-1) and any halo chunk issued then
+                wait_vm(issued);
+                if (c == 3 && tg == 2) {
+                    // ---- epilogue of this tile (registers + global memory only; overlaps nothing in LDS)
+                    const int m = (int)cur_m;
+                    const int ty = cur_t / tiles_x;
+                    const int y0 = ty * T4_H, x0 = (cur_t - ty * tiles_x) * T4_W;
+                    size_t oimg = (size_t)m;
+                    if (p.out_h > 0) { const int ob = m / p.out_h, oi = m - ob * p.out_h; oimg = (size_t)ob * p.out_vs + oi; }
+                    unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * 256;
+                    const int gx = x0 + r;
+                    const unsigned char* rv[2] = {nullptr, nullptr};        // residual: view i (couts 0..63), partner (64..127)
+                    if (RES) {
+                        const int b = m / p.pair_h, i = m - b * p.pair_h;
+                        rv[0] = (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + i) * hw * 128;
+                        rv[1] = (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + (p.pair_last - i)) * hw * 128;
+                    }
+                    auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
+                        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb) {
+                            const int gy = y0 + 2 * w + pb;
+                            const bool ok = gy < H && gx < W;
+                            const int gyc = gy < H ? gy : H - 1, gxc = gx < W ? gx : W - 1;
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr) {            // cout blocks (2pr, 2pr+1) -> channels 64pr + 32hh ..
+                                u32x4 rq[4];
+                                if (RES) {
+                                    const u32x4* rp = (const u32x4*)(rv[pr] + (unsigned)((gyc * W + gxc) * 128 + hh * 64));
+#pragma unroll
+                                    for (int g = 0; g < 4; ++g) rq[g] = rp[g];
+                                }
+                                u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * 256 + pr * 128) + lane_out);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    float xa[4], xb[4];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) { xa[j] = acc[2 * pr][pb][4 * g + j]; xb[j] = acc[2 * pr + 1][pb][4 * g + j]; }
+                                    if (ACT == 1) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) { xa[j] = raw_max4(xa[j], slope * xa[j]); xb[j] = raw_max4(xb[j], slope * xb[j]); }
+                                    } else if (ACT == 2) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) { xa[j] = xa[j] >= 0.f ? xa[j] : slope * xa[j]; xb[j] = xb[j] >= 0.f ? xb[j] : slope * xb[j]; }
+                                    }
+                                    // v_permlane32_swap(a, b): lanes 32..63 of a <-> lanes 0..31 of b; afterwards a lane holds
+                                    // (a, b) = channels 64pr + 32hh + 8g + (0..3, 4..7) of its pixel
+                                    u32x4 u;
+                                    if (RES) {
+                                        float v[8];
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) {
+                                            const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa[j]), __float_as_uint(xb[j]), false, false);
+                                            v[j] = __uint_as_float(sw[0]);
+                                            v[4 + j] = __uint_as_float(sw[1]);
+                                        }
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) {
+                                            v[2 * j] += __uint_as_float(rq[g][j] << 16);
+                                            v[2 * j + 1] += __uint_as_float(rq[g][j] & 0xffff0000u);
+                                        }
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) u[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
+                                    } else {
+                                        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pack2_bf16(xa[0], xa[1]), pack2_bf16(xb[0], xb[1]), false, false);
+                                        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pack2_bf16(xa[2], xa[3]), pack2_bf16(xb[2], xb[3]), false, false);
+                                        u[0] = s0[0]; u[1] = s1[0]; u[2] = s0[1]; u[3] = s1[1];
+                                    }
+                                    if (ok) op[g] = u;
+                                }
+                            }
+                        }
+                    };
+                    if (!has_slope) epilogue(std::integral_constant<int, 0>{});
+                    else if (slope01) epilogue(std::integral_constant<int, 1>{});
+                    else epilogue(std::integral_constant<int, 2>{});
+                }
+                lds_done_then_barrier4();
+            }
+        }
+        cur_m = nxt_m; cur_t = nxt_t;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last stages' look-ahead DMAs must not outlive the workgroup
+}
+
+int g_v4_cus = 0;
+
+template <bool RES>
+int launch_v4(const ConvParams& p, long grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HRN_HIP(hipFuncSetAttribute((const void*)conv3x3_v4_kernel<RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_v4_kernel<RES>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// bf16 128 -> 128, residual none or the pair gather (res_mode 2).  Returns -100 when not applicable.
+int hrn_launch_conv3x3_v4(const ConvParams& p, hipStream_t stream) {
+    if (p.scale || p.relu || (p.res_mode != 0 && p.res_mode != 2)) return -100;
+    if ((p.in_pair || p.res_mode == 2) && p.pair_h <= 0) return -100;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    if (g_v4_cus == 0) {
+        int dev = 0, n = 0;
+        HRN_HIP(hipGetDevice(&dev));
+        HRN_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        g_v4_cus = n > 0 ? n : 256;
+    }
+    const long tiles = (long)((p.W + T4_W - 1) / T4_W) * ((p.H + T4_H - 1) / T4_H);
+    const long total = tiles * p.M;
+    HRN_CHECK(total > 0, -2, "conv3x3_v4: bad tile count %ld", total);
+    if (total >= (1L << 30) || (long)p.H * p.W * 256 >= (1L << 31)) return -100;     // 32-bit tile / in-image byte arithmetic
+    long grid = g_v4_cus;
+    if (total < grid) grid = total;
+    if (grid >= 8) grid &= ~7L;
+    const double px = (double)p.M * p.H * p.W;
+    HrnProfScope prof(p.res_mode ? "conv3x3_bf16_128x128+res" : "conv3x3_bf16_128x128", 2.0 * 128 * 128 * 9 * px,
+                      px * 2 * (128 + 128 + (p.res_mode ? 128 : 0)), stream);
+    return p.res_mode ? launch_v4<true>(p, grid, stream) : launch_v4<false>(p, grid, stream);
+}
