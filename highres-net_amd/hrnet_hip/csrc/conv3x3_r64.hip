@@ -11,11 +11,15 @@
 // 512 threads = two teams of four waves, one wave of each team on every SIMD.  The teams alternate:
 //     ON  phase: 36 k-steps (9 taps x 4) on the team's halo tile - one uninterrupted hand-pipelined ds_read/MFMA stream,
 //                no weight traffic, no address arithmetic beyond one v_xor per fragment, no barrier inside;
-//     OFF phase: fetch the team's next halo tile HBM -> VGPR, finish the tile just multiplied straight from the
-//                accumulators (bias, PReLU, v_permlane32_swap so every lane owns 64 contiguous bytes of one pixel,
-//                residual, one bf16 rounding, 16-byte stores), commit the fetched tile into the team's LDS buffer.
+//                the tile's residual is fetched HBM -> VGPR at its start;
+//     OFF phase: start the LDS-DMA (global_load_lds_dwordx4) of the team's next halo tile straight into the team's LDS
+//                buffer - no staging registers, no ds_write; the bank swizzle is applied to each lane's SOURCE address -
+//                then finish the tile just multiplied from the accumulators (bias pre-loaded, PReLU, v_permlane32_swap
+//                so every lane owns 64 contiguous bytes of one pixel, residual, one bf16 rounding, 16-byte stores),
+//                then wait (counted vmcnt: the tile's own stores stay in flight) for the DMAs.
 // One workgroup barrier per phase.  While team A's waves occupy the matrix pipe, team B's waves on the same SIMDs do the
-// VALU / VMEM / ds_write work, so neither the epilogue nor the input staging costs MFMA time.
+// VALU / VMEM work, so neither the epilogue nor the input staging costs MFMA time.  No ordinary global load is issued in
+// the OFF phase: beside an LDS-DMA in flight hipcc waits vmcnt(0) for any of them, which would drain the DMAs early.
 // Same math / layouts / packed weights / persistent XCD-windowed tile walk as the other conv kernels.
 #include <type_traits>
 #include "conv3x3.h"
@@ -25,11 +29,9 @@ namespace {
 constexpr int HALO_H = CONV_TILE_H + 2;
 constexpr int HALO_W = CONV_TILE_W + 2;
 constexpr int IN_BYTES = HALO_H * HALO_W * 128;              // 43,520 (unpadded, swizzled)
-constexpr int N_IN_PIECES = HALO_H * HALO_W * 8;             // 2,720
 constexpr int W_BYTES = 9 * 64 * 128;                        // 73,728
 constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + 256;
 constexpr int TEAM = 256;                                    // threads per team
-constexpr int PI = (N_IN_PIECES + TEAM - 1) / TEAM;          // 11 halo pieces per thread
 
 __device__ __forceinline__ void lds_done_then_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -45,6 +47,8 @@ __device__ __forceinline__ float raw_max(float a, float b) {
     return y;
 }
 
+__device__ __attribute__((aligned(16))) unsigned hrn_r64_zero16[4];
+
 template <bool RES>
 __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int team = wave >> 2, tw = wave & 3, tt = tid & (TEAM - 1);
+    const int team = wave >> 2, tw = wave & 3;
     unsigned char* in_lds = smem + W_BYTES + team * IN_BYTES;
     const int r = lane & 31, hh = lane >> 5;
     const int H = p.H, W = p.W;
@@ -86,61 +90,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
         if (tid < 64) bias_lds[tid] = p.bias[tid];
     }
 
-    // ---- halo tile: HBM -> VGPR (issue) and VGPR -> this team's LDS buffer (commit)
-    // Piece map of a team thread tq (16-byte piece `part` = tq & 7 of one halo pixel), chosen so that no division is
-    // needed and the row test is wave-uniform:
-    //     pieces 0..9 : halo row it, halo column tq >> 3 (0..31)
-    //     piece  10   : threads tq < 160 only: halo row tq >> 4, halo column 32 + ((tq >> 3) & 1)
-    // The geometry is recomputed from an opaque copy of the thread index: left to itself the compiler keeps 40+
-    // loop-invariant registers of it alive through the MFMA phase and spills.
-    u32x4 reg[PI];
-    unsigned okmask = 0;                                    // bit it: piece `it` lies inside the image
-    bool edge = false;                                      // the fetched tile has out-of-image halo pixels (uniform)
+    // ---- halo tile of (m, t): HBM -> this team's LDS buffer by LDS-DMA.  Wave tw of the team issues pieces j = tw, tw+4,
+    // ... < 43; piece j, lane i -> LDS bytes j*1024 + i*16 = halo pixel j*8 + (i >> 3), physical 16-B chunk i & 7, which
+    // holds logical chunk (i & 7) ^ ((pixel >> 1) & 7).  Out-of-image pixels are read from a zero line; the half-empty
+    // last piece is EXEC-masked.  The geometry is recomputed from an opaque copy of the lane id so that it does not sit
+    // in registers through the MFMA phase.
     auto issue = [&](unsigned m, unsigned t) __attribute__((always_inline)) {
         const int ty = t / tiles_x;
         const int y0 = ty * CONV_TILE_H, x0 = (t - ty * tiles_x) * CONV_TILE_W;
         const unsigned char* base = (const unsigned char*)p.in + (size_t)m * hw * 128;     // uniform: image base
-        edge = y0 < 1 || y0 + CONV_TILE_H + 1 > H || x0 < 1 || x0 + CONV_TILE_W + 1 > W;
-        int tq = tt;
-        asm volatile("" : "+v"(tq));
-        const int part = tq & 7, cg = tq >> 3;
-        const int gx = x0 - 1 + cg;
-        const bool xok = (unsigned)gx < (unsigned)W;
-        const int off0 = ((y0 - 1) * W + gx) * 128 + part * 16;
-        unsigned okm = 0;
+        int lq = lane;
+        asm volatile("" : "+v"(lq));
 #pragma unroll
-        for (int it = 0; it < PI - 1; ++it) {
-            const bool ok = xok && (unsigned)(y0 - 1 + it) < (unsigned)H;
-            // branch-free: out-of-image pieces read byte 0 of the image and are zeroed at commit time
-            reg[it] = *(const u32x4*)(base + (ok ? (unsigned)(off0 + it * W * 128) : 0u));
-            okm |= (unsigned)ok << it;
+        for (int jj = 0; jj < 11; ++jj) {
+            const int j = tw + 4 * jj;
+            if (j < 43) {
+                const int pix = j * 8 + (lq >> 3);
+                const int lc = (lq & 7) ^ ((pix >> 1) & 7);
+                const int py = pix / HALO_W, px = pix - py * HALO_W;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const unsigned char* src = ok ? base + (unsigned)((gy * W + gx) * 128 + lc * 16) : (const unsigned char*)hrn_r64_zero16;
+                if (pix < HALO_H * HALO_W)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(in_lds + j * 1024), 16, 0, 0);
+            }
         }
-        {
-            const int gy2 = y0 - 1 + (tq >> 4), gx2 = x0 + 31 + (cg & 1);
-            const bool ok = tq < 160 && (unsigned)gy2 < (unsigned)H && (unsigned)gx2 < (unsigned)W;
-            reg[PI - 1] = *(const u32x4*)(base + (ok ? (unsigned)((gy2 * W + gx2) * 128 + part * 16) : 0u));
-            okm |= (unsigned)ok << (PI - 1);
-        }
-        okmask = okm;
-    };
-    auto commit = [&]() __attribute__((always_inline)) {
-        int tq = tt;
-        asm volatile("" : "+v"(tq));
-        const int part = tq & 7, cg = tq >> 3;
-        if (edge) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int it = 0; it < PI; ++it) reg[it] = (okmask >> it) & 1u ? reg[it] : z;
-        }
-#pragma unroll
-        for (int it = 0; it < PI - 1; ++it) {
-            const int pix = it * HALO_W + cg;
-            *(u32x4*)(in_lds + pix * 128 + ((part ^ ((pix >> 1) & 7)) << 4)) = reg[it];
-        }
-        if (tq < 160) {
-            const int pix = (tq >> 4) * HALO_W + 32 + (cg & 1);
-            *(u32x4*)(in_lds + pix * 128 + ((part ^ ((pix >> 1) & 7)) << 4)) = reg[PI - 1];
-        }
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     const bool has_slope = p.slope != nullptr;
@@ -205,6 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
     // ---- residual of the tile at the cursor: the 64 bytes this lane will own after the swap (channels 32*hh .. 32*hh+31
     // of its pixel).  Fetched at the START of the ON phase, consumed in the OFF phase - a whole K loop of latency cover.
     u32x4 resv[2][4];
+    float res_alpha = 1.f;
     auto fetch_residual = [&]() __attribute__((always_inline)) {
         const int m = (int)cur_m;
         const int ty = cur_t / tiles_x;
@@ -213,6 +190,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
         if (p.res_mode == 3) {
             const int ob = m / p.out_h, oi = m - ob * p.out_h;
             rbase = (const unsigned char*)p.res + ((size_t)ob * p.res_vs + oi) * hw * 128;
+            res_alpha = p.alphas ? p.alphas[(size_t)ob * p.alpha_vs + (p.pair_last - oi)] : 1.f;
         }
         const int gx = x0 + r, gxc = gx < W ? gx : W - 1;
 #pragma unroll
@@ -237,8 +215,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
         // uniform base at the tile origin; per-lane byte offset of (row 2*tw, column r, channel half hh) is tile-independent
         unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * 128;
         const int gx = x0 + r;
-        float res_alpha = 1.f;
-        if (RES && p.res_mode == 3 && p.alphas) res_alpha = p.alphas[(size_t)ob * p.alpha_vs + (p.pair_last - oi)];
+        if (RES) {                                          // make the residual's wait happen BEFORE the DMAs are issued
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(resv[pb][g]));
+            asm volatile("" :: "v"(res_alpha));
+        }
         if (more) issue(cur_m, cur_t);                      // in flight while the epilogue runs
         // ACT 0: no activation | 1: PReLU with 0 <= slope <= 1 as max(x, slope*x) (2 VALU) | 2: general PReLU (3 VALU)
         auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
@@ -291,10 +274,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
         if (!has_slope) epilogue(std::integral_constant<int, 0>{});
         else if (slope01) epilogue(std::integral_constant<int, 1>{});
         else epilogue(std::integral_constant<int, 2>{});
-        if (more) commit();
+        {   // the halo DMAs were issued before this tile's stores: wait until only those stores are outstanding
+            const int nst = 4 * ((y0 + 2 * tw < H) + (y0 + 2 * tw + 1 < H));
+            if (nst == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     };
 
-    if (nmine > 0) { issue(cur_m, cur_t); commit(); }
+    if (nmine > 0) issue(cur_m, cur_t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_done_then_barrier();                                // weights, bias, both teams' first halo tiles
 
     // phase ph: team 0 is at step q = ph, team 1 at q = ph - 1; even q = ON (tile q/2), odd q = OFF (tile (q-1)/2)
