@@ -31,7 +31,6 @@ constexpr int HALO_W = CONV_TILE_W + 2;
 constexpr int IN_BYTES = HALO_H * HALO_W * 128;              // 43,520 (unpadded, swizzled)
 constexpr int W_BYTES = 9 * 64 * 128;                        // 73,728
 constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + 256;
-constexpr int TEAM = 256;                                    // threads per team
 
 __device__ __forceinline__ void lds_done_then_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
