@@ -78,6 +78,29 @@ def _check_config(config):
             "2->64 stem, 64-channel 3x3 convs, stride-3 k3 deconv, 1x1 final; got " + repr(config))
 
 
+class _HRNetTrainFunction(torch.autograd.Function):
+    """`srs = fusion_model(lrs, alphas)` ... `loss.backward()` (train.py:172-190) on the HIP kernels: hrn_hrnet_forward_train keeps
+    every intermediate in a workspace, hrn_hrnet_backward turns d_sr into the parameter gradients.  lrs / alphas get none."""
+
+    @staticmethod
+    def forward(ctx, module, names, lrs, alphas, *params):
+        packed = module._packed_f32()
+        sr, tws = binding.hrnet_forward_train(packed, lrs, alphas, module._num_layers, module.fuse.alpha_residual)
+        ctx.module, ctx.names, ctx.packed, ctx.tws = module, names, packed, tws
+        ctx.save_for_backward(lrs, alphas, *params)
+        return sr
+
+    @staticmethod
+    def backward(ctx, d_sr):
+        lrs, alphas, *params = ctx.saved_tensors
+        named = dict(zip(ctx.names, params))
+        grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in named.items()}
+        binding.hrnet_backward(ctx.packed, named, grads, ctx.module._num_layers, ctx.module.fuse.alpha_residual, lrs, alphas,
+                               d_sr.contiguous(), ctx.tws)
+        ctx.tws = None
+        return (None, None, None, None) + tuple(grads[k].to(named[k].dtype) for k in ctx.names)
+
+
 class HRNet(nn.Module):
     """HRNet(config["network"]); forward(lrs (B,L,H,W), alphas (B,L)) -> (B,1,3H,3W)."""
 
@@ -114,12 +137,28 @@ class HRNet(nn.Module):
         if lrs.shape[2] != lrs.shape[3]:
             raise ValueError("square low-res images only: the reference reinterprets (H,W) as (W,H) in its .view() "
                              "(HRNet.py:204), which is the identity only for H == W")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError(
-                "backward kernels are not built yet (SURVEY.md section 8 row f3): run the HIP HRNet under torch.no_grad() "
-                "or in eval() mode")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training path (.train() mode with grad enabled; fp32 kernels whatever `precision` says): a forward that keeps its
+            # intermediates + the HIP backward.  In .eval() mode (validation, train.py:196-215; predict.py) the inference
+            # kernels run and the result carries no autograd graph.
+            names = [k for k, _ in self.named_parameters()]
+            return _HRNetTrainFunction.apply(self, names, lrs.detach(), alphas.detach(), *[p for _, p in self.named_parameters()])
         packed, dt = self.packed_parameters()
         return binding.hrnet_forward(packed, dt, self._num_layers, self.fuse.alpha_residual, lrs.detach(), alphas.detach())
+
+    def _packed_f32(self):
+        named = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in named.values())
+        if getattr(self, "_packed32", None) is None or self._packed32_key != key:
+            slopes = torch.stack([p.detach().reshape(()) for k, p in named.items() if p.numel() == 1 and k.endswith(".weight")
+                                  and ("block.1" in k or "block.3" in k or k.endswith("init_layer.1.weight")
+                                       or k.endswith("fuse.2.weight") or k.endswith("deconv.1.weight"))])
+            if not bool((slopes > 0).all()):
+                raise NotImplementedError("the HIP backward works from stored post-activations and needs every PReLU slope > 0 "
+                                          "(the reference initialises them to 0.25)")
+            self._packed32 = binding.hrnet_pack(named, self._num_layers, binding.F32)
+            self._packed32_key = key
+        return self._packed32
 
     # -- staged access for parity tests / profiling (channels-last tensors in the storage dtype)
     def encode_views(self, lrs):

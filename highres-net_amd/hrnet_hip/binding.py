@@ -59,6 +59,11 @@ SIGNATURES = {
                                     _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_decoder_forward": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_void_p, _c.c_void_p]),
+    "hrn_hrnet_train_workspace_bytes": (_c.c_size_t, [_c.c_int] * 5),
+    "hrn_hrnet_forward_train": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_hrnet_backward": (_c.c_int, [_c.c_void_p, _c.POINTER(HrnetParams), _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
+                                      _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(HrnetParams), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_shiftnet_packed_bytes": (_c.c_size_t, []),
     "hrn_shiftnet_pack": (_c.c_int, [_c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_shiftnet_workspace_bytes": (_c.c_size_t, [_c.c_int]),
@@ -128,9 +133,8 @@ def _ptr(t):
 
 
 # --------------------------------------------------------------------------- HRNet
-def hrnet_pack(named, num_layers, dtype):
-    """named: dict of reference state-dict keys -> device f32 tensors.  Returns the packed uint8 tensor."""
-    lib = load_library()
+def hrnet_param_struct(named, num_layers):
+    """named: dict of reference state-dict keys -> device f32 tensors.  Returns (HrnetParams, tensors kept alive)."""
     keep = []
 
     def p(key):
@@ -154,6 +158,13 @@ def hrnet_pack(named, num_layers, dtype):
     P.fuse_out_w, P.fuse_out_b, P.fuse_out_a = p("fuse.fuse.1.weight"), p("fuse.fuse.1.bias"), p("fuse.fuse.2.weight")
     P.dec_w, P.dec_b, P.dec_a = p("decode.deconv.0.weight"), p("decode.deconv.0.bias"), p("decode.deconv.1.weight")
     P.fin_w, P.fin_b = p("decode.final.weight"), p("decode.final.bias")
+    return P, keep
+
+
+def hrnet_pack(named, num_layers, dtype):
+    """named: dict of reference state-dict keys -> device f32 tensors.  Returns the packed uint8 tensor."""
+    lib = load_library()
+    P, keep = hrnet_param_struct(named, num_layers)
     nbytes = lib.hrn_hrnet_packed_bytes(dtype, num_layers)
     if nbytes == 0:
         raise HrnetHipError(f"unsupported dtype/num_layers ({dtype}, {num_layers})")
@@ -237,6 +248,43 @@ def hrnet_decoder(packed, dtype, num_layers, fused):
         sr = torch.empty((N, 1, 3 * H, 3 * W), dtype=torch.float32, device=fused.device)
         _check(lib.hrn_decoder_forward(_ptr(packed), dtype, num_layers, _ptr(fused), N, H, W, _ptr(sr), _stream()), "hrn_decoder_forward")
     return sr
+
+
+def hrnet_forward_train(packed_f32, lrs, alphas, num_layers, alpha_residual):
+    """Training forward (fp32): returns (sr, train_ws); train_ws holds every intermediate for hrnet_backward."""
+    lib = load_library()
+    lrs = _dev_f32(lrs, "lrs")
+    alphas = _dev_f32(alphas, "alphas")
+    B, V, H, W = lrs.shape
+    nbytes = lib.hrn_hrnet_train_workspace_bytes(num_layers, B, V, H, W)
+    if nbytes == 0:
+        raise HrnetHipError(f"bad training shape B={B} V={V} H={H} W={W} num_layers={num_layers}")
+    tws = torch.empty(nbytes, dtype=torch.uint8, device=lrs.device)
+    sr = torch.empty((B, 1, 3 * H, 3 * W), dtype=torch.float32, device=lrs.device)
+    with torch.cuda.device(lrs.device):
+        _check(lib.hrn_hrnet_forward_train(_ptr(packed_f32), num_layers, int(bool(alpha_residual)), _ptr(lrs), _ptr(alphas),
+                                           B, V, H, W, _ptr(sr), _ptr(tws), nbytes, _stream()), "hrn_hrnet_forward_train")
+    return sr, tws
+
+
+def hrnet_backward(packed_f32, named_params, named_grads, num_layers, alpha_residual, lrs, alphas, d_sr, tws):
+    """Accumulates dLoss/dparam into named_grads (same keys / shapes as named_params, f32, zero them for plain gradients)."""
+    lib = load_library()
+    lrs = _dev_f32(lrs, "lrs")
+    alphas = _dev_f32(alphas, "alphas")
+    d_sr = _dev_f32(d_sr, "d_sr")
+    B, V, H, W = lrs.shape
+    if tuple(d_sr.shape) != (B, 1, 3 * H, 3 * W):
+        raise ValueError(f"d_sr shape {tuple(d_sr.shape)} != {(B, 1, 3 * H, 3 * W)}")
+    P, keep_p = hrnet_param_struct(named_params, num_layers)
+    G, keep_g = hrnet_param_struct(named_grads, num_layers)
+    for t, g in zip(keep_p, keep_g):
+        if t.shape != g.shape or g.data_ptr() == t.data_ptr():
+            raise ValueError("gradient buffers must match the parameters' shapes and not alias them")
+    with torch.cuda.device(lrs.device):
+        _check(lib.hrn_hrnet_backward(_ptr(packed_f32), ctypes.byref(P), int(bool(alpha_residual)), _ptr(lrs), _ptr(alphas),
+                                      B, V, H, W, _ptr(d_sr), ctypes.byref(G), _ptr(tws), tws.numel(), _stream()),
+               "hrn_hrnet_backward")
 
 
 # --------------------------------------------------------------------------- ShiftNet

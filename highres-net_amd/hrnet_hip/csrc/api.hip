@@ -2,6 +2,7 @@
 // and workspace layouts, and the kernel sequences of HRNet.forward / ShiftNet.forward.
 #include "../../../include/hrnet_hip.h"
 #include "kernels.h"
+#include "hrnet_layout.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -18,35 +19,7 @@ void hrn_set_error(const char* fmt, ...) {
 
 namespace {
 
-constexpr size_t ALIGN = 256;
-
-// ---------------------------------------------------------------- HRNet packed parameter layout (byte offsets)
-struct HrnetLayout {
-    size_t stem_w, stem_b, stem_a;
-    size_t enc_w[2 * HRN_MAX_RES_LAYERS], enc_b[2 * HRN_MAX_RES_LAYERS], enc_a[2 * HRN_MAX_RES_LAYERS];
-    size_t encf_w, encf_b;
-    size_t fres_w[2], fres_b[2], fres_a[2];
-    size_t fout_w, fout_b, fout_a;
-    size_t dec_w, dec_b, dec_a, fin_w, fin_b;
-    size_t total;
-};
-
-HrnetLayout hrnet_layout(int dt, int nl) {
-    HrnetLayout L;
-    memset(&L, 0, sizeof L);
-    const size_t es = hrn_esize(dt);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = hrn_align_up(off + bytes, ALIGN); return o; };
-    L.stem_w = take(64 * 18 * 4); L.stem_b = take(64 * 4); L.stem_a = take(4);
-    for (int i = 0; i < 2 * nl; ++i) { L.enc_w[i] = take(64 * 64 * 9 * es); L.enc_b[i] = take(64 * 4); L.enc_a[i] = take(4); }
-    L.encf_w = take(64 * 64 * 9 * es); L.encf_b = take(64 * 4);
-    for (int i = 0; i < 2; ++i) { L.fres_w[i] = take(128 * 128 * 9 * es); L.fres_b[i] = take(128 * 4); L.fres_a[i] = take(4); }
-    L.fout_w = take(128 * 64 * 9 * es); L.fout_b = take(64 * 4); L.fout_a = take(4);
-    L.dec_w = take(64 * 64 * 9 * es); L.dec_b = take(64 * 4); L.dec_a = take(4);
-    L.fin_w = take(64 * 4); L.fin_b = take(4);
-    L.total = off;
-    return L;
-}
+using namespace hrn;     // packed-parameter layout, at(), conv_base(): hrnet_layout.h
 
 // ---------------------------------------------------------------- HRNet workspace layout
 struct HrnetWs {
@@ -67,21 +40,11 @@ HrnetWs hrnet_ws(int dt, int B, int V, int H, int W) {
     return w;
 }
 
-inline const unsigned char* at(const void* base, size_t off) { return (const unsigned char*)base + off; }
-inline unsigned char* at(void* base, size_t off) { return (unsigned char*)base + off; }
-
 int check_common(int dt, int nl, int B, int V, int H, int W) {
     HRN_CHECK(dt == HRN_F32 || dt == HRN_BF16, -2, "dtype must be HRN_DTYPE_F32 or HRN_DTYPE_BF16 (got %d)", dt);
     HRN_CHECK(nl >= 0 && nl <= HRN_MAX_RES_LAYERS, -2, "num_layers %d out of range 0..%d", nl, HRN_MAX_RES_LAYERS);
     HRN_CHECK(B > 0 && V > 0 && H > 0 && W > 0, -2, "empty input B=%d V=%d H=%d W=%d", B, V, H, W);
     return 0;
-}
-
-ConvParams conv_base(int M, int H, int W) {
-    ConvParams p;
-    memset(&p, 0, sizeof p);
-    p.M = M; p.H = H; p.W = W;
-    return p;
 }
 
 int encoder_impl(const void* pk, int dt, int nl, const float* lrs, int B, int V, int H, int W,

@@ -1,0 +1,35 @@
+// Launchers of the backward building blocks (backward.hip).  Same conventions as kernels.h: asynchronous on `stream`, no
+// allocation, no synchronisation; gradients are ACCUMULATED (+=) into their destination, like autograd's .grad.
+#pragma once
+#include "common.h"
+
+// bytes of the `scratch` buffer the launchers below share (wgrad partial slabs, reduction partials)
+size_t hrn_bwd_scratch_bytes(int num_cus);
+
+// g = dy * PReLU'(x) from the post-activation y; dslope[0] += sum dy * min(x, 0).  g may alias dy.  n elements, n % 4 == 0.
+int hrn_launch_prelu_bwd(const float* dy, const float* y, const float* slope, float* g, size_t n, float* dslope, void* scratch,
+                         hipStream_t s);
+// db[c] += sum_rows g[row][c], C in {64, 128}
+int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scratch, hipStream_t s);
+// wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]: the OIHW tensor whose forward convolution is the data gradient
+int hrn_launch_dgrad_weights(const float* w, float* wt, int cin, int cout, hipStream_t s);
+// dw[co][ci][3][3] += sum g (x) shifted x; x plain [M][H][W][cin] or the pair gather of `stack` (cin = 128)
+int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int pair_h, int pair_last, int pair_vs, const float* g,
+                          int M, int H, int W, int cin, int cout, float* dw, void* scratch, int num_cus, hipStream_t s);
+// stem 2 -> 64: in0 = image m (stride0 floats apart), in1 = plane m / rep1; dw [64][2][3][3]
+int hrn_launch_stem_wgrad(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* g, int M, int H,
+                          int W, float* dw, void* scratch, int num_cus, hipStream_t s);
+int hrn_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t s);
+// fusion level helpers (HRNet.py:113-132): forward update of the kept views, and the two backward maps
+int hrn_launch_fuse_update(const float* stack, int n_in, const float* f, const float* alphas, int alpha_vs, int pair_last, int half,
+                           int alpha_residual, float* out, size_t hw, int B, hipStream_t s);
+int hrn_launch_fuse_df(const float* dsn, const float* alphas, int alpha_vs, int pair_last, int half, int alpha_residual, float* df,
+                       size_t hw, int B, hipStream_t s);
+int hrn_launch_fuse_scatter(const float* dsn, const float* dz, int n_in, int half, int pair_last, int alpha_residual, float* ds,
+                            size_t hw, int B, hipStream_t s);
+// Decoder backward (HRNet.py:147-156,167-169): fused [N][H][W][64] f32, d_sr [N][3H][3W]; reference-layout parameters
+// wd (64,64,3,3) = (Cin,Cout,kH,kW), bd (64), ad (1), wf (64), bf (1).  Writes d_fused; accumulates the five gradients.
+int hrn_launch_decoder_bwd(const float* fused, const float* d_sr, const float* wd, const float* bd, const float* ad, const float* wf,
+                           float* d_fused, float* dwd, float* dbd, float* dad, float* dwf, float* dbf, int N, int H, int W,
+                           void* scratch, int num_cus, hipStream_t s);
+size_t hrn_decoder_bwd_scratch_bytes(int num_cus);

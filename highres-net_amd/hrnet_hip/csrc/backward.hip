@@ -1,0 +1,432 @@
+// Backward building blocks of the HRNet training path (fp32, NHWC): SURVEY.md section 8f row f3, `loss.backward()` through
+// HRNet in src/train.py:190.  Everything here is deterministic: reductions go through per-workgroup partial sums in a
+// workspace and a fixed-order finish kernel - no float atomics.
+//
+//   prelu_bwd      g = dy * (y > 0 ? 1 : a), da += sum dy * min(x, 0)          (nn.PReLU, HRNet.py:19,21,53,97,151)
+//                  from the POST-activation y the forward stored: x < 0 <=> y < 0 and min(x, 0) = y / a, valid for a > 0
+//                  (the reference initialises a = 0.25; a <= 0 is rejected on the Python side)
+//   colsum         db[c] += sum over pixels of g[pixel][c]                        (conv bias gradient)
+//   conv wgrad     dW[co][ci][ky][kx] += sum_pixels g[p][co] * x[p + (ky-1, kx-1)][ci]   (nn.Conv2d 3x3 pad 1 weight gradient)
+//                  exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) with K = pixels: A = g^T, B = shifted x, both read as single
+//                  floats from LDS tiles; one wave owns a 32 x 32 (cout, cin) block for all nine taps (144 accumulators)
+//                  and keeps it across every tile of its persistent workgroup
+//   stem wgrad     the same for the 2 -> 64 stem (fp32 planes as input, VALU)
+//   dgrad          needs no kernel: dx = conv3x3(g, W^T with taps flipped) runs on the forward kernel after
+//                  hrn_launch_dgrad_weights() has produced the transposed OIHW tensor
+#include "kernels.h"
+#include "backward.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 512;         // partial sums per reduction
+
+// ------------------------------------------------------------------------------------------------ PReLU backward
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ slope, float* __restrict__ g, size_t n4,
+                                                        double* __restrict__ partial) {
+    const float a = slope[0];
+    const float inv_a = a != 0.f ? 1.f / a : 0.f;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 d = ((const f32x4*)dy)[i], v = ((const f32x4*)y)[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = v[j] > 0.f;
+            o[j] = pos ? d[j] : a * d[j];
+            // the slope gradient is a sum of signed terms that largely cancel: accumulate it in fp64
+            if (!pos) acc += (double)d[j] * ((double)v[j] * (double)inv_a);
+        }
+        ((f32x4*)g)[i] = o;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void scalar_finish_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += partial[i];
+        out[0] += (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums (bias grads)
+template <int C>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, size_t rows, double* __restrict__ partial) {
+    // thread -> channel c = tid % C, row phase tid / C; rows strided by gridDim * (256 / C)
+    constexpr int RP = 256 / C;
+    const int c = threadIdx.x % C, rp = threadIdx.x / C;
+    double acc = 0.0;
+    for (size_t r = (size_t)blockIdx.x * RP + rp; r < rows; r += (size_t)gridDim.x * RP) acc += (double)g[r * C + c];
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rp == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < RP; ++k) s += red[k * C + c];
+        partial[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+__global__ void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
+    out[c] += (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ dgrad weights
+// w [co][ci][3][3] -> wt [ci][co][3][3] with taps flipped: wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]
+__global__ void dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin, int cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cin * cout * 9;
+    if (idx >= total) return;
+    const int tap = idx % 9, co = (idx / 9) % cout, ci = idx / (9 * cout);
+    wt[idx] = w[((size_t)co * cin + ci) * 9 + (8 - tap)];
+}
+
+// ------------------------------------------------------------------------------------------------ conv weight gradient
+// One persistent workgroup of 256 threads per CU walks 8 x 32-pixel tiles.  Per tile, LDS holds the g tile [256 px][64 co]
+// and the x halo tile [10 x 34 px][64 ci] for one (cout chunk, cin chunk) pair of 64 x 64; wave w owns the 32 x 32 block
+// (cb, ib) = (w >> 1, w & 1) for all 9 taps.  MFMA 32x32x2: k = two consecutive pixels of the tile.
+constexpr int WG_TH = 8, WG_TW = 32, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;
+constexpr int WG_XP = 64 + 4;           // floats per halo pixel in LDS (+4: the hh = 1 lanes land on other banks)
+constexpr int WG_GP = 64 + 4;
+constexpr int WG_LDS = (WG_HH * WG_HW * WG_XP + WG_TH * WG_TW * WG_GP) * 4;     // 92,480 + 69,632 = 162,112 B
+
+struct WgradParams {
+    const float* x;         // plain input [M][H][W][CIN] (in_pair == 0)
+    const float* stack;     // pair gather: views [B][pair_vs][H][W][64]
+    int in_pair, pair_h, pair_last, pair_vs;
+    const float* g;         // [M][H][W][COUT]
+    float* partial;         // [gridDim.x][9][64][64] for this (cout chunk, cin chunk)
+    int M, H, W, cin, cout, co_chunk, ci_chunk;
+};
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* xs = (float*)smem;                                   // [340][WG_XP]
+    float* gs = xs + WG_HH * WG_HW * WG_XP;                     // [256][WG_GP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int cb = wave >> 1, ib = wave & 1;
+    const int H = p.H, W = p.W;
+    const size_t hw = (size_t)H * W;
+    const int tiles_x = (W + WG_TW - 1) / WG_TW, tiles_y = (H + WG_TH - 1) / WG_TH;
+    const long tiles = (long)tiles_x * tiles_y, total = tiles * p.M;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    for (long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+        const int m = (int)(tl / tiles);
+        const int t = (int)(tl - (long)m * tiles);
+        const int ty = t / tiles_x, y0 = ty * WG_TH, x0 = (t - ty * tiles_x) * WG_TW;
+        // source of the cin chunk: plain tensor, or view i / partner view of the pair gather (64 channels each)
+        const float* xb;
+        int xpitch;
+        if (p.in_pair) {
+            const int b = m / p.pair_h, i = m - b * p.pair_h;
+            const int v = p.ci_chunk == 0 ? i : p.pair_last - i;
+            xb = p.stack + ((size_t)b * p.pair_vs + v) * hw * 64;
+            xpitch = 64;
+        } else {
+            xb = p.x + (size_t)m * hw * p.cin + p.ci_chunk * 64;
+            xpitch = p.cin;
+        }
+        const float* gb = p.g + (size_t)m * hw * p.cout + p.co_chunk * 64;
+        __syncthreads();                                        // previous tile's MFMA reads are done
+        // x halo tile: 340 px x 16 float4
+        for (int q = tid; q < WG_HH * WG_HW * 16; q += 256) {
+            const int pix = q >> 4, part = q & 15;
+            const int py = pix / WG_HW, px = pix - py * WG_HW;
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *(const f32x4*)(xb + ((size_t)gy * W + gx) * xpitch + part * 4);
+            *(f32x4*)(xs + pix * WG_XP + part * 4) = v;
+        }
+        // g tile: 256 px x 16 float4 (zero outside the image: those pixels contribute nothing)
+        for (int q = tid; q < WG_TH * WG_TW * 16; q += 256) {
+            const int pix = q >> 4, part = q & 15;
+            const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy < H && gx < W) v = *(const f32x4*)(gb + ((size_t)gy * W + gx) * p.cout + part * 4);
+            *(f32x4*)(gs + pix * WG_GP + part * 4) = v;
+        }
+        __syncthreads();
+        // 128 k-steps of two pixels: A[co = r][k = hh] = g[pixel 2s + hh][cb*32 + r], B[k = hh][ci = r] = x[pixel + tap][ib*32 + r]
+        const float* ga = gs + hh * WG_GP + cb * 32 + r;
+        const float* xa = xs + hh * WG_XP + ib * 32 + r;
+#pragma unroll 2
+        for (int s = 0; s < 128; ++s) {
+            const int pp = 2 * s;                               // even pixel of the pair; both pixels share the tile row
+            const int row = pp >> 5, col = pp & 31;
+            const float a = ga[pp * WG_GP];
+            const float* xr = xa + (row * WG_HW + col) * WG_XP;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float b = xr[(ky * WG_HW + kx) * WG_XP];
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * 3 + kx], 0, 0, 0);
+                }
+        }
+    }
+    // partial[blk][tap][co 64][ci 64]; accumulator element (g4, j) of lane (r = ci column, hh) is row co = 8*g4 + 4*hh + j
+    float* out = p.partial + (size_t)blockIdx.x * 9 * 4096;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = cb * 32 + 8 * g4 + 4 * hh + j;
+                out[(size_t)t * 4096 + co * 64 + ib * 32 + r] = acc[t][4 * g4 + j];
+            }
+}
+
+// dW[co][ci][tap] (OIHW, full cin/cout) += sum over workgroups of partial[blk][tap][co_l][ci_l]
+__global__ void wgrad_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dw, int cin, int co_chunk,
+                                    int ci_chunk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over 9 * 64 * 64
+    if (idx >= 9 * 4096) return;
+    const int tap = idx / 4096, co_l = (idx >> 6) & 63, ci_l = idx & 63;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * 9 * 4096 + idx];
+    const int co = co_chunk * 64 + co_l, ci = ci_chunk * 64 + ci_l;
+    dw[((size_t)co * cin + ci) * 9 + tap] += (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ stem weight gradient
+// dW[co][c2][tap] += sum g[m][p][co] * in_c2[m][p + tap], in_0 = view m, in_1 = reference frame of sample m / rep1
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ in0, size_t stride0, const float* __restrict__ in1,
+                                                         int rep1, size_t stride1, const float* __restrict__ g, int M, int H, int W,
+                                                         float* __restrict__ partial) {
+    __shared__ float tile[2][WG_HH][WG_HW];
+    const int tid = threadIdx.x, co = tid & 63, q = tid >> 6;
+    const int tiles_x = (W + WG_TW - 1) / WG_TW, tiles_y = (H + WG_TH - 1) / WG_TH;
+    const long tiles = (long)tiles_x * tiles_y, total = tiles * M;
+    const size_t hw = (size_t)H * W;
+    float acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0.f;
+    for (long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+        const int m = (int)(tl / tiles);
+        const int t = (int)(tl - (long)m * tiles);
+        const int ty = t / tiles_x, y0 = ty * WG_TH, x0 = (t - ty * tiles_x) * WG_TW;
+        const float* p0 = in0 + (size_t)m * stride0;
+        const float* p1 = in1 + (size_t)(m / rep1) * stride1;
+        __syncthreads();
+        for (int i = tid; i < 2 * WG_HH * WG_HW; i += 256) {
+            const int c = i / (WG_HH * WG_HW), pix = i - c * WG_HH * WG_HW;
+            const int py = pix / WG_HW, px = pix - py * WG_HW;
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            float v = 0.f;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = (c == 0 ? p0 : p1)[(size_t)gy * W + gx];
+            tile[c][py][px] = v;
+        }
+        __syncthreads();
+        const float* gb = g + (size_t)m * hw * 64 + co;
+        for (int pix = q; pix < WG_TH * WG_TW; pix += 4) {
+            const int py = pix >> 5, px = pix & 31;
+            const int gy = y0 + py, gx = x0 + px;
+            if (gy >= H || gx >= W) continue;
+            const float gv = gb[((size_t)gy * W + gx) * 64];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[c * 9 + ky * 3 + kx] += gv * tile[c][py + ky][px + kx];
+        }
+    }
+    // partial[blk][q][co][18]
+    float* out = partial + ((size_t)blockIdx.x * 4 + q) * 64 * 18 + co * 18;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) out[k] = acc[k];
+}
+__global__ void stem_wgrad_finish_kernel(const float* __restrict__ partial, int nrows, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over 64 * 18, dw layout [co][c2][3][3] = co*18 + c*9 + tap
+    if (idx >= 64 * 18) return;
+    double s = 0.0;
+    for (int b = 0; b < nrows; ++b) s += (double)partial[(size_t)b * 64 * 18 + idx];
+    dw[idx] += (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise helpers
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        ((f32x4*)o)[i] = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+}
+
+// fusion level, forward: s'[b][i] = s[b][i] + alpha[b][partner(i)] * f[b][i]   (or s' = f without the alpha residual)
+__global__ __launch_bounds__(256) void fuse_update_kernel(const float* __restrict__ stack, int n_in, const float* __restrict__ f,
+                                                          const float* __restrict__ alphas, int alpha_vs, int pair_last, int half,
+                                                          int alpha_residual, float* __restrict__ out, size_t img4, int B) {
+    const size_t total = (size_t)B * half * img4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t img = i / img4, e = i - img * img4;
+        const int b = (int)(img / half), v = (int)(img - (size_t)b * half);
+        const f32x4 fv = ((const f32x4*)f)[i];
+        if (alpha_residual) {
+            const float al = alphas[(size_t)b * alpha_vs + (pair_last - v)];
+            ((f32x4*)out)[i] = ((const f32x4*)stack)[((size_t)b * n_in + v) * img4 + e] + al * fv;
+        } else {
+            ((f32x4*)out)[i] = fv;
+        }
+    }
+}
+// fusion level, backward: df[b][i] = alpha_partner * ds'[b][i]  (or ds')
+__global__ __launch_bounds__(256) void fuse_df_kernel(const float* __restrict__ dsn, const float* __restrict__ alphas, int alpha_vs,
+                                                      int pair_last, int half, int alpha_residual, float* __restrict__ df, size_t img4,
+                                                      int B) {
+    const size_t total = (size_t)B * half * img4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t img = i / img4;
+        const int b = (int)(img / half), v = (int)(img - (size_t)b * half);
+        const float al = alpha_residual ? alphas[(size_t)b * alpha_vs + (pair_last - v)] : 1.f;
+        ((f32x4*)df)[i] = al * ((const f32x4*)dsn)[i];
+    }
+}
+// fusion level, backward: gradient of the level's input views from ds' (alice pass-through, alpha residual only) and
+// dz [B*half][HW][128] (channels 0..63 -> view i, 64..127 -> view pair_last - i); views that took no part get zero
+__global__ __launch_bounds__(256) void fuse_scatter_kernel(const float* __restrict__ dsn, const float* __restrict__ dz, int n_in, int half,
+                                                           int pair_last, int alpha_residual, float* __restrict__ ds, size_t hw, int B) {
+    const size_t img4 = hw * 16;                                // float4 per 64-channel image
+    const size_t total = (size_t)B * n_in * img4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t img = i / img4, e = i - img * img4;
+        const int b = (int)(img / n_in), v = (int)(img - (size_t)b * n_in);
+        const size_t pix = e >> 4, part = e & 15;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (v < half) {
+            if (alpha_residual) o = ((const f32x4*)dsn)[((size_t)b * half + v) * img4 + e];
+            o += ((const f32x4*)dz)[(((size_t)b * half + v) * hw + pix) * 32 + part];
+        } else if (v <= pair_last && pair_last - v < half) {
+            o = ((const f32x4*)dz)[(((size_t)b * half + (pair_last - v)) * hw + pix) * 32 + 16 + part];
+        }
+        ((f32x4*)ds)[i] = o;
+    }
+}
+
+int red_grid(size_t n4) {
+    size_t g = (n4 + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+size_t hrn_bwd_scratch_bytes(int num_cus) {
+    // wgrad partial slabs (one (cout chunk, cin chunk) pair at a time) + reduction partials
+    return (size_t)num_cus * 9 * 4096 * 4 + (size_t)RED_BLOCKS * 128 * 8 + 4096;
+}
+
+int hrn_launch_prelu_bwd(const float* dy, const float* y, const float* slope, float* g, size_t n, float* dslope, void* scratch,
+                         hipStream_t s) {
+    HRN_CHECK(n % 4 == 0, -2, "prelu_bwd: element count %zu not a multiple of 4", n);
+    double* partial = (double*)scratch;
+    const int blocks = RED_BLOCKS;
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, y, slope, g, n / 4, partial);
+    hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, dslope);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scratch, hipStream_t s) {
+    HRN_CHECK(C == 64 || C == 128, -2, "colsum: C must be 64 or 128 (got %d)", C);
+    double* partial = (double*)scratch;
+    const int blocks = RED_BLOCKS;
+    if (C == 64) hipLaunchKernelGGL(colsum_kernel<64>, dim3(blocks), dim3(256), 0, s, g, rows, partial);
+    else hipLaunchKernelGGL(colsum_kernel<128>, dim3(blocks), dim3(256), 0, s, g, rows, partial);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(128), 0, s, partial, blocks, C, db);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_dgrad_weights(const float* w, float* wt, int cin, int cout, hipStream_t s) {
+    const int total = cin * cout * 9;
+    hipLaunchKernelGGL(dgrad_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, wt, cin, cout);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int pair_h, int pair_last, int pair_vs, const float* g,
+                          int M, int H, int W, int cin, int cout, float* dw, void* scratch, int num_cus, hipStream_t s) {
+    HRN_CHECK((cin == 64 || cin == 128) && (cout == 64 || cout == 128), -2, "conv_wgrad: unsupported %d -> %d", cin, cout);
+    HRN_CHECK(!in_pair || cin == 128, -2, "conv_wgrad: the pair gather has 128 input channels");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HRN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
+        attr_set = true;
+    }
+    static_assert(WG_LDS <= 160 * 1024, "LDS budget");
+    const long tiles = (long)((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * M;
+    int grid = num_cus;
+    if (tiles < grid) grid = (int)tiles;
+    WgradParams p;
+    p.x = x; p.stack = stack; p.in_pair = in_pair; p.pair_h = pair_h; p.pair_last = pair_last; p.pair_vs = pair_vs;
+    p.g = g; p.partial = (float*)scratch; p.M = M; p.H = H; p.W = W; p.cin = cin; p.cout = cout;
+    for (int cc = 0; cc < cout / 64; ++cc)
+        for (int ic = 0; ic < cin / 64; ++ic) {
+            p.co_chunk = cc; p.ci_chunk = ic;
+            hipLaunchKernelGGL(conv_wgrad_kernel, dim3(grid), dim3(256), WG_LDS, s, p);
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((9 * 4096 + 255) / 256), dim3(256), 0, s, (const float*)scratch, grid, dw, cin, cc, ic);
+        }
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_stem_wgrad(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* g, int M, int H,
+                          int W, float* dw, void* scratch, int num_cus, hipStream_t s) {
+    const long tiles = (long)((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * M;
+    int grid = num_cus;
+    if (tiles < grid) grid = (int)tiles;
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, g, M, H, W, (float*)scratch);
+    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3((64 * 18 + 255) / 256), dim3(256), 0, s, (const float*)scratch, grid * 4, dw);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t s) {
+    HRN_CHECK(n % 4 == 0, -2, "add: element count %zu not a multiple of 4", n);
+    hipLaunchKernelGGL(add_kernel, dim3(red_grid(n / 4)), dim3(256), 0, s, a, b, o, n / 4);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_fuse_update(const float* stack, int n_in, const float* f, const float* alphas, int alpha_vs, int pair_last, int half,
+                           int alpha_residual, float* out, size_t hw, int B, hipStream_t s) {
+    const size_t img4 = hw * 16;
+    hipLaunchKernelGGL(fuse_update_kernel, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, stack, n_in, f, alphas, alpha_vs,
+                       pair_last, half, alpha_residual, out, img4, B);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_fuse_df(const float* dsn, const float* alphas, int alpha_vs, int pair_last, int half, int alpha_residual, float* df,
+                       size_t hw, int B, hipStream_t s) {
+    const size_t img4 = hw * 16;
+    hipLaunchKernelGGL(fuse_df_kernel, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, dsn, alphas, alpha_vs, pair_last, half,
+                       alpha_residual, df, img4, B);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_fuse_scatter(const float* dsn, const float* dz, int n_in, int half, int pair_last, int alpha_residual, float* ds,
+                            size_t hw, int B, hipStream_t s) {
+    hipLaunchKernelGGL(fuse_scatter_kernel, dim3(red_grid((size_t)B * n_in * hw * 16)), dim3(256), 0, s, dsn, dz, n_in, half, pair_last,
+                       alpha_residual, ds, hw, B);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,266 @@
+// Training path of HRNet (fp32): a forward that keeps what the backward needs, and the backward itself
+// (`srs = fusion_model(lrs, alphas)` ... `loss.backward()`, src/train.py:172-190).
+//
+// Forward (HRNet.py:186-211) is the inference kernel sequence with every intermediate kept in the training workspace:
+//   encoder   a0 = PReLU(stem);  h_l = PReLU(conv(a_l));  r_l = PReLU(conv(h_l));  a_{l+1} = a_l + r_l;  stack_0 = conv(a_nl)
+//   level     z = cat(s_i, s_partner);  t1 = PReLU(convA(z));  u = PReLU(convB(t1));  t2 = z + u;  f = PReLU(convC(t2));
+//             stack_{l+1}[i] = s_i + alpha_partner f   (i < n/2)
+//   decoder   sr = conv1x1(PReLU(deconv(stack_T)))
+// Backward walks it in reverse with three primitives per convolution: PReLU backward on the stored post-activation
+// (+ slope gradient), the weight/bias gradient (backward.hip), and the data gradient, which is the forward convolution
+// kernel run on the transposed, tap-flipped weights.  All gradients are accumulated (+=) into the caller's buffers.
+#include "../../../include/hrnet_hip.h"
+#include "kernels.h"
+#include "backward.h"
+#include "hrnet_layout.h"
+
+using namespace hrn;
+
+namespace {
+
+constexpr int TMAX = 16;
+
+struct TrainWs {
+    int T;                                  // fusion levels
+    int n_in[TMAX + 1];                     // views entering level l (n_in[T] = views left at the end)
+    size_t ref, a[HRN_MAX_RES_LAYERS + 1], h[HRN_MAX_RES_LAYERS], r[HRN_MAX_RES_LAYERS];
+    size_t stack[TMAX + 1], t1[TMAX], u[TMAX], t2[TMAX], f[TMAX];
+    size_t g[5];                            // backward: five gradient buffers of one full activation each
+    size_t wt, wtp, zero_bias, scratch;
+    size_t total;
+};
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, c = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) n = c;
+        else n = 256;
+    }
+    return n;
+}
+
+TrainWs train_ws(int nl, int B, int V, int H, int W) {
+    TrainWs w;
+    memset(&w, 0, sizeof w);
+    const size_t hw = (size_t)H * W;
+    const size_t S = (size_t)B * V * hw * 64 * 4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = hrn_align_up(off + bytes, ALIGN); return o; };
+    w.ref = take((size_t)B * hw * 4);
+    for (int l = 0; l <= nl; ++l) w.a[l] = take(S);
+    for (int l = 0; l < nl; ++l) { w.h[l] = take(S); w.r[l] = take(S); }
+    int n = V, T = 0;
+    w.n_in[0] = V;
+    w.stack[0] = take(S);
+    while (n / 2 > 0 && T < TMAX) {
+        const int half = n / 2;
+        const size_t s128 = (size_t)B * half * hw * 128 * 4, s64 = (size_t)B * half * hw * 64 * 4;
+        w.t1[T] = take(s128); w.u[T] = take(s128); w.t2[T] = take(s128); w.f[T] = take(s64);
+        w.stack[T + 1] = take(s64);
+        n = half;
+        ++T;
+        w.n_in[T] = n;
+    }
+    w.T = T;
+    for (int i = 0; i < 5; ++i) w.g[i] = take(S);
+    w.wt = take((size_t)128 * 128 * 9 * 4);
+    w.wtp = take((size_t)128 * 128 * 9 * 4);
+    w.zero_bias = take(128 * 4);
+    size_t sc = hrn_bwd_scratch_bytes(num_cus());
+    const size_t sd = hrn_decoder_bwd_scratch_bytes(num_cus());
+    if (sd > sc) sc = sd;
+    w.scratch = take(sc);
+    w.total = off;
+    return w;
+}
+
+int check_train(int nl, int B, int V, int H, int W) {
+    HRN_CHECK(nl >= 0 && nl <= HRN_MAX_RES_LAYERS, -2, "num_layers %d out of range 0..%d", nl, HRN_MAX_RES_LAYERS);
+    HRN_CHECK(B > 0 && V > 0 && H > 0 && W > 0, -2, "empty input B=%d V=%d H=%d W=%d", B, V, H, W);
+    HRN_CHECK(V < (1 << TMAX), -2, "too many views (%d)", V);
+    return 0;
+}
+
+// y = conv3x3(x) (+ PReLU) on the forward f32 kernel
+int conv_fwd(int cin, int cout, const void* x, void* y, const void* wpk, const float* bias, const float* slope, int M, int H, int W,
+             hipStream_t s) {
+    ConvParams p = conv_base(M, H, W);
+    p.in = x; p.out = y; p.wpk = wpk; p.bias = bias; p.slope = slope;
+    return hrn_launch_conv3x3(HRN_F32, cin, cout, p, s);
+}
+
+// dx = conv3x3(g, W^T flipped) (+ res): the data gradient of a cin -> cout convolution with raw weights w [cout][cin][3][3]
+int conv_dgrad(int cin, int cout, const float* w, const float* g, float* dx, const float* res, int M, int H, int W, void* tws,
+               const TrainWs& L, hipStream_t s) {
+    int rc;
+    float* wt = (float*)at(tws, L.wt);
+    void* wtp = at(tws, L.wtp);
+    if ((rc = hrn_launch_dgrad_weights(w, wt, cin, cout, s))) return rc;
+    if ((rc = hrn_launch_conv_pack(HRN_F32, cout, cin, wt, wtp, s))) return rc;           // a cout -> cin convolution
+    ConvParams p = conv_base(M, H, W);
+    p.in = g; p.out = dx; p.wpk = wtp; p.bias = (const float*)at(tws, L.zero_bias); p.slope = nullptr;
+    if (res) { p.res = res; p.res_mode = 1; }
+    return hrn_launch_conv3x3(HRN_F32, cout, cin, p, s);
+}
+
+// z + u for the pair gather z of a level: t2[b*half + i][p][c] = (c < 64 ? s_i : s_partner)[p][c % 64] + u[...]
+__global__ __launch_bounds__(256) void pair_add_kernel(const float* __restrict__ stack, int n_in, int half, int pair_last,
+                                                       const float* __restrict__ u, float* __restrict__ t2, size_t hw, int B) {
+    const size_t total = (size_t)B * half * hw * 32;            // float4 units, 32 per pixel
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pixg = i >> 5;
+        const int part = (int)(i & 31);
+        const size_t img = pixg / hw, pix = pixg - img * hw;
+        const int b = (int)(img / half), v = (int)(img - (size_t)b * half);
+        const int src = part < 16 ? v : pair_last - v;
+        const f32x4 z = ((const f32x4*)stack)[(((size_t)b * n_in + src) * hw + pix) * 16 + (part & 15)];
+        ((f32x4*)t2)[i] = z + ((const f32x4*)u)[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hrn_hrnet_train_workspace_bytes(int num_layers, int B, int V, int H, int W) {
+    if (num_layers < 0 || num_layers > HRN_MAX_RES_LAYERS || B <= 0 || V <= 0 || H <= 0 || W <= 0 || V >= (1 << TMAX)) return 0;
+    return train_ws(num_layers, B, V, H, W).total;
+}
+
+int hrn_hrnet_forward_train(const void* pk, int nl, int alpha_residual, const float* lrs, const float* alphas, int B, int V, int H, int W,
+                            float* sr, void* tws, size_t tws_bytes, void* stream) {
+    int rc;
+    if ((rc = check_train(nl, B, V, H, W))) return rc;
+    HRN_CHECK(pk && lrs && alphas && sr && tws, -2, "hrn_hrnet_forward_train: null argument");
+    const TrainWs L = train_ws(nl, B, V, H, W);
+    HRN_CHECK(tws_bytes >= L.total, -3, "hrn_hrnet_forward_train: workspace too small (%zu < %zu)", tws_bytes, L.total);
+    const HrnetLayout P = hrnet_layout(HRN_F32, nl);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t hw = (size_t)H * W;
+    const int M = B * V;
+    float* ref = (float*)at(tws, L.ref);
+    if ((rc = hrn_launch_median(lrs, ref, B, V, H, W, s))) return rc;
+    if ((rc = hrn_launch_stem(HRN_F32, lrs, hw, ref, V, hw, nullptr, (const float*)at(pk, P.stem_w), (const float*)at(pk, P.stem_b),
+                              (const float*)at(pk, P.stem_a), at(tws, L.a[0]), M, H, W, s))) return rc;
+    for (int l = 0; l < nl; ++l) {
+        if ((rc = conv_fwd(64, 64, at(tws, L.a[l]), at(tws, L.h[l]), at(pk, P.enc_w[2 * l]), (const float*)at(pk, P.enc_b[2 * l]),
+                           (const float*)at(pk, P.enc_a[2 * l]), M, H, W, s))) return rc;
+        if ((rc = conv_fwd(64, 64, at(tws, L.h[l]), at(tws, L.r[l]), at(pk, P.enc_w[2 * l + 1]), (const float*)at(pk, P.enc_b[2 * l + 1]),
+                           (const float*)at(pk, P.enc_a[2 * l + 1]), M, H, W, s))) return rc;
+        if ((rc = hrn_launch_add((const float*)at(tws, L.a[l]), (const float*)at(tws, L.r[l]), (float*)at(tws, L.a[l + 1]),
+                                 (size_t)M * hw * 64, s))) return rc;
+    }
+    if ((rc = conv_fwd(64, 64, at(tws, L.a[nl]), at(tws, L.stack[0]), at(pk, P.encf_w), (const float*)at(pk, P.encf_b), nullptr, M, H, W, s)))
+        return rc;
+    for (int t = 0; t < L.T; ++t) {
+        const int n = L.n_in[t], half = n / 2, pair_last = n - (n & 1) - 1;
+        const float* st = (const float*)at(tws, L.stack[t]);
+        ConvParams a = conv_base(B * half, H, W);
+        a.in_pair = 1; a.stack = st; a.pair_h = half; a.pair_last = pair_last; a.pair_vs = n;
+        a.out = at(tws, L.t1[t]);
+        a.wpk = at(pk, P.fres_w[0]); a.bias = (const float*)at(pk, P.fres_b[0]); a.slope = (const float*)at(pk, P.fres_a[0]);
+        if ((rc = hrn_launch_conv3x3(HRN_F32, 128, 128, a, s))) return rc;
+        if ((rc = conv_fwd(128, 128, at(tws, L.t1[t]), at(tws, L.u[t]), at(pk, P.fres_w[1]), (const float*)at(pk, P.fres_b[1]),
+                           (const float*)at(pk, P.fres_a[1]), B * half, H, W, s))) return rc;
+        {
+            const size_t total4 = (size_t)B * half * hw * 32;
+            size_t grid = (total4 + 255) / 256;
+            if (grid > 4096) grid = 4096;
+            hipLaunchKernelGGL(pair_add_kernel, dim3((unsigned)grid), dim3(256), 0, s, st, n, half, pair_last, (const float*)at(tws, L.u[t]),
+                               (float*)at(tws, L.t2[t]), hw, B);
+            HRN_LAUNCH_CHECK();
+        }
+        if ((rc = conv_fwd(128, 64, at(tws, L.t2[t]), at(tws, L.f[t]), at(pk, P.fout_w), (const float*)at(pk, P.fout_b),
+                           (const float*)at(pk, P.fout_a), B * half, H, W, s))) return rc;
+        if ((rc = hrn_launch_fuse_update(st, n, (const float*)at(tws, L.f[t]), alphas, V, pair_last, half, alpha_residual,
+                                         (float*)at(tws, L.stack[t + 1]), hw, B, s))) return rc;
+    }
+    // views left after the last level: 1 (or V itself for V == 1); torch.mean over them (HRNet.py:134) is the identity
+    return hrn_launch_decoder(HRN_F32, at(tws, L.stack[L.T]), at(pk, P.dec_w), (const float*)at(pk, P.dec_b), (const float*)at(pk, P.dec_a),
+                              (const float*)at(pk, P.fin_w), (const float*)at(pk, P.fin_b), sr, B, H, W, s);
+}
+
+int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_residual, const float* lrs, const float* alphas, int B, int V,
+                       int H, int W, const float* d_sr, const hrn_hrnet_params* Gr, void* tws, size_t tws_bytes, void* stream) {
+    int rc;
+    HRN_CHECK(pk && Pr && Gr && lrs && alphas && d_sr && tws, -2, "hrn_hrnet_backward: null argument");
+    const int nl = Pr->num_layers;
+    if ((rc = check_train(nl, B, V, H, W))) return rc;
+    const TrainWs L = train_ws(nl, B, V, H, W);
+    HRN_CHECK(tws_bytes >= L.total, -3, "hrn_hrnet_backward: workspace too small (%zu < %zu)", tws_bytes, L.total);
+    const HrnetLayout P = hrnet_layout(HRN_F32, nl);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t hw = (size_t)H * W;
+    const int M = B * V, cus = num_cus();
+    void* sc = at(tws, L.scratch);
+    float* G[5];
+    for (int i = 0; i < 5; ++i) G[i] = (float*)at(tws, L.g[i]);
+    HRN_HIP(hipMemsetAsync(at(tws, L.zero_bias), 0, 128 * 4, s));
+    // gradients are handed over as mutable buffers in a params-shaped struct
+    auto mut = [](const float* p) { return const_cast<float*>(p); };
+
+    // ---- decoder: d_sr -> d stack_T (one view left)                                  HRNet.py:147-156,167-169
+    float* dsn = G[0];                      // gradient of the views leaving the current level
+    if ((rc = hrn_launch_decoder_bwd((const float*)at(tws, L.stack[L.T]), d_sr, Pr->dec_w, Pr->dec_b, Pr->dec_a, Pr->fin_w, dsn,
+                                     mut(Gr->dec_w), mut(Gr->dec_b), mut(Gr->dec_a), mut(Gr->fin_w), mut(Gr->fin_b), B, H, W, sc, cus, s)))
+        return rc;
+
+    // ---- fusion levels, last to first                                                HRNet.py:113-132
+    for (int t = L.T - 1; t >= 0; --t) {
+        const int n = L.n_in[t], half = n / 2, pair_last = n - (n & 1) - 1, Mh = B * half;
+        const float* st = (const float*)at(tws, L.stack[t]);
+        // every G buffer holds B*V*hw*64 floats; Mh <= B*V/2, so one buffer also holds an [Mh][hw][128] tensor
+        float* y1 = G[1];                   // d t2               [Mh][hw][128]; dead before ds is written into the same buffer
+        float* ds = G[1];                   // gradient of the views entering the level  [B*n][hw][64]
+        float* x1 = G[2];                   // df / gC            [Mh][hw][64]
+        float* y3 = G[3];                   // d t1 / gA          [Mh][hw][128]
+        float* y2 = G[4];                   // gB, later dz       [Mh][hw][128]
+        if ((rc = hrn_launch_fuse_df(dsn, alphas, V, pair_last, half, alpha_residual, x1, hw, B, s))) return rc;
+        // f = PReLU(convC(t2))
+        if ((rc = hrn_launch_prelu_bwd(x1, (const float*)at(tws, L.f[t]), Pr->fuse_out_a, x1, (size_t)Mh * hw * 64, mut(Gr->fuse_out_a), sc, s))) return rc;
+        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t2[t]), nullptr, 0, 0, 0, 0, x1, Mh, H, W, 128, 64, mut(Gr->fuse_out_w), sc, cus, s))) return rc;
+        if ((rc = hrn_launch_colsum(x1, (size_t)Mh * hw, 64, mut(Gr->fuse_out_b), sc, s))) return rc;
+        if ((rc = conv_dgrad(128, 64, Pr->fuse_out_w, x1, y1, nullptr, Mh, H, W, tws, L, s))) return rc;
+        // t2 = z + u, u = PReLU(convB(t1))
+        if ((rc = hrn_launch_prelu_bwd(y1, (const float*)at(tws, L.u[t]), Pr->fuse_res_a[1], y2, (size_t)Mh * hw * 128, mut(Gr->fuse_res_a[1]), sc, s))) return rc;
+        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t1[t]), nullptr, 0, 0, 0, 0, y2, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[1]), sc, cus, s))) return rc;
+        if ((rc = hrn_launch_colsum(y2, (size_t)Mh * hw, 128, mut(Gr->fuse_res_b[1]), sc, s))) return rc;
+        if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[1], y2, y3, nullptr, Mh, H, W, tws, L, s))) return rc;
+        // t1 = PReLU(convA(z))
+        if ((rc = hrn_launch_prelu_bwd(y3, (const float*)at(tws, L.t1[t]), Pr->fuse_res_a[0], y3, (size_t)Mh * hw * 128, mut(Gr->fuse_res_a[0]), sc, s))) return rc;
+        if ((rc = hrn_launch_conv_wgrad(nullptr, st, 1, half, pair_last, n, y3, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[0]), sc, cus, s))) return rc;
+        if ((rc = hrn_launch_colsum(y3, (size_t)Mh * hw, 128, mut(Gr->fuse_res_b[0]), sc, s))) return rc;
+        if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[0], y3, y2, y1, Mh, H, W, tws, L, s))) return rc;     // dz = d t2 + dgradA(gA)
+        // dz -> the two views of each pair (+ the alice pass-through)
+        if ((rc = hrn_launch_fuse_scatter(dsn, y2, n, half, pair_last, alpha_residual, ds, hw, B, s))) return rc;
+        float* tmp = G[0]; G[0] = G[1]; G[1] = tmp;
+        dsn = G[0];
+    }
+
+    // ---- encoder                                                                     HRNet.py:51-60,62-74
+    float* dA = G[1];
+    if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.a[nl]), nullptr, 0, 0, 0, 0, dsn, M, H, W, 64, 64, mut(Gr->enc_final_w), sc, cus, s))) return rc;
+    if ((rc = hrn_launch_colsum(dsn, (size_t)M * hw, 64, mut(Gr->enc_final_b), sc, s))) return rc;
+    if ((rc = conv_dgrad(64, 64, Pr->enc_final_w, dsn, dA, nullptr, M, H, W, tws, L, s))) return rc;
+    float* e2 = G[2];
+    float* e3 = G[3];
+    for (int l = nl - 1; l >= 0; --l) {
+        // a_{l+1} = a_l + r_l,  r_l = PReLU(conv2(h_l)),  h_l = PReLU(conv1(a_l))
+        if ((rc = hrn_launch_prelu_bwd(dA, (const float*)at(tws, L.r[l]), Pr->enc_res_a[2 * l + 1], e2, (size_t)M * hw * 64, mut(Gr->enc_res_a[2 * l + 1]), sc, s))) return rc;
+        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.h[l]), nullptr, 0, 0, 0, 0, e2, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l + 1]), sc, cus, s))) return rc;
+        if ((rc = hrn_launch_colsum(e2, (size_t)M * hw, 64, mut(Gr->enc_res_b[2 * l + 1]), sc, s))) return rc;
+        if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l + 1], e2, e3, nullptr, M, H, W, tws, L, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd(e3, (const float*)at(tws, L.h[l]), Pr->enc_res_a[2 * l], e3, (size_t)M * hw * 64, mut(Gr->enc_res_a[2 * l]), sc, s))) return rc;
+        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.a[l]), nullptr, 0, 0, 0, 0, e3, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l]), sc, cus, s))) return rc;
+        if ((rc = hrn_launch_colsum(e3, (size_t)M * hw, 64, mut(Gr->enc_res_b[2 * l]), sc, s))) return rc;
+        if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l], e3, e2, dA, M, H, W, tws, L, s))) return rc;       // d a_l = d a_{l+1} + dgrad1(g1)
+        float* tmp = dA; dA = e2; e2 = tmp;
+    }
+    // stem: a_0 = PReLU(conv(cat(view, reference frame)))                               HRNet.py:200-204, :51-53
+    if ((rc = hrn_launch_prelu_bwd(dA, (const float*)at(tws, L.a[0]), Pr->enc_init_a, dA, (size_t)M * hw * 64, mut(Gr->enc_init_a), sc, s))) return rc;
+    if ((rc = hrn_launch_stem_wgrad(lrs, hw, (const float*)at(tws, L.ref), V, hw, dA, M, H, W, mut(Gr->enc_init_w), sc, cus, s))) return rc;
+    return hrn_launch_colsum(dA, (size_t)M * hw, 64, mut(Gr->enc_init_b), sc, s);
+}
+
+}  // extern "C"

@@ -90,6 +90,20 @@ int hrn_fuse_forward(const void* packed, int dtype, int num_layers, int alpha_re
 int hrn_decoder_forward(const void* packed, int dtype, int num_layers, const void* fused, int N, int H, int W,
                         float* sr, void* stream);
 
+/* Training path (fp32 only): `srs = fusion_model(lrs, alphas)` with grad enabled and `loss.backward()` through HRNet,
+ * src/train.py:172-190.  hrn_hrnet_forward_train is hrn_hrnet_forward(HRN_DTYPE_F32) with every intermediate kept in
+ * `train_ws`; hrn_hrnet_backward consumes that workspace (same B, V, H, W) and d_sr = dLoss/d sr (B,1,3H,3W) and
+ * ACCUMULATES (+=, like autograd's .grad) the parameter gradients into the buffers `grads` points at - the same struct,
+ * fields aliasing f32 gradient tensors of the parameters' shapes (the inputs lrs / alphas get no gradient, as in
+ * train.py).  `packed` is the HRN_DTYPE_F32 blob of hrn_hrnet_pack, `params` the raw reference-layout tensors.
+ * PReLU slopes must be > 0 (the backward works from stored post-activations). */
+size_t hrn_hrnet_train_workspace_bytes(int num_layers, int B, int V, int H, int W);
+int hrn_hrnet_forward_train(const void* packed, int num_layers, int alpha_residual, const float* lrs, const float* alphas,
+                            int B, int V, int H, int W, float* sr, void* train_ws, size_t train_ws_bytes, void* stream);
+int hrn_hrnet_backward(const void* packed, const hrn_hrnet_params* params, int alpha_residual, const float* lrs,
+                       const float* alphas, int B, int V, int H, int W, const float* d_sr, const hrn_hrnet_params* grads,
+                       void* train_ws, size_t train_ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ ShiftNet */
 typedef struct hrn_shiftnet_params {
     const float* conv_w[8];       /* layerN.0.weight  (co,ci,3,3): 2->64,64->64 x3,64->128,128->128 x3 */

@@ -1,0 +1,100 @@
+"""GPU (-m gpu): the HRNet training path (`loss.backward()` through HRNet, train.py:172-190).
+
+Oracle: torch autograd on the CPU through oracle/torch_port.hrnet_forward (the restatement the goldens pin), run in float64,
+with the same seeded weights and inputs.  The HIP path goes HRNet.forward (grad enabled) -> hrn_hrnet_forward_train ->
+loss.backward() -> hrn_hrnet_backward, all fp32.  Tolerance: 2e-4 relative per parameter tensor (max-norm), fp32
+accumulation over up to 1e5 pixels; measured ~1e-6..1e-5.  No reference-side golden exists for gradients: the reference's
+own backward is torch autograd over the same operator sequence, which is what the oracle side runs here.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth, torch_port, weights
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh_model(alpha_residual=True, seed=1234):
+    from DeepNetworks.HRNet import HRNet
+    cfg = {k: dict(v) for k, v in weights.HRNET_CONFIG.items()}
+    cfg["recursive"]["alpha_residual"] = alpha_residual
+    m = HRNet(cfg)
+    m.load_state_dict(weights.to_torch_state(weights.hrnet_state(seed)))
+    return m.cuda().train()
+
+
+def _oracle_grads(lrs, alphas, cot, alpha_residual, seed=1234):
+    st = {k: v.double().requires_grad_(True) for k, v in weights.to_torch_state(weights.hrnet_state(seed)).items()}
+    with torch.enable_grad():
+        sr = torch_port.hrnet_forward.__wrapped__(torch.from_numpy(lrs).double(), torch.from_numpy(alphas).double(), st,
+                                                  num_layers=weights.HRNET_CONFIG["encoder"]["num_layers"], alpha_residual=alpha_residual)
+        (sr * torch.from_numpy(cot).double()).sum().backward()
+    # parameters the graph never touched (the fusion block when V == 1) have no gradient in torch: zero here
+    return sr.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in st.items()}
+
+
+@pytest.mark.parametrize("B,V,S,n_real,alpha_residual", [
+    (2, 4, 16, 4, True),        # power of two
+    (2, 5, 16, 4, True),        # odd view count (one view unpaired at the first level), one padded view
+    (1, 7, 24, 7, True),        # 24 x 24: partial tiles in both directions; odd at two levels
+    (2, 6, 16, 6, False),       # alpha_residual = false branch (HRNet.py:123)
+    (2, 1, 16, 1, True),        # a single view: no fusion level at all
+])
+def test_hrnet_backward_vs_autograd_oracle(B, V, S, n_real, alpha_residual):
+    lrs, alphas, _ = synth.make_batch(5, B, V, S, n_real)
+    rng = np.random.Generator(np.random.PCG64(77))
+    cot = rng.standard_normal((B, 1, 3 * S, 3 * S)).astype(np.float32)
+    want_sr, want = _oracle_grads(lrs, alphas, cot, alpha_residual)
+    m = _fresh_model(alpha_residual)
+    sr = m(util.dev(lrs), util.dev(alphas))
+    assert sr.requires_grad
+    assert util.rel_err(sr.detach().cpu().numpy(), want_sr) <= 2e-5
+    (sr * util.dev(cot)).sum().backward()
+    # PReLU-slope / scalar gradients are sums of ~1e4..1e5 signed terms that can cancel to a small net value (the stem's at
+    # V = 1: 0.026 against 12..37 for the other slopes; CPU fp32 autograd is itself 2e-4 off the fp64 value there), so
+    # scalars are held to 2e-4 of the LARGEST scalar gradient of the model, tensors to 2e-4 of their own max-norm.
+    scalar_scale = max(float(np.abs(want[k]).max()) for k, p in m.named_parameters() if p.numel() == 1)
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        got = p.grad.cpu().numpy()
+        if p.numel() == 1:
+            assert abs(float(got.ravel()[0]) - float(want[k].ravel()[0])) <= 2e-4 * scalar_scale, (k, got, want[k])
+        else:
+            e = util.rel_err(got, want[k])
+            assert e <= 2e-4, (k, e)
+    # a second backward pass accumulates into .grad like autograd does
+    sr2 = m(util.dev(lrs), util.dev(alphas))
+    (sr2 * util.dev(cot)).sum().backward()
+    k0, p0 = next(iter(m.named_parameters()))
+    assert util.rel_err(p0.grad.cpu().numpy(), 2 * want[k0]) <= 2e-4
+
+
+def test_hrnet_train_step_reduces_loss():
+    """A few Adam steps on the HIP forward/backward drive a plain L2 loss down; eval forward sees the updated weights."""
+    lrs, alphas, _ = synth.make_batch(9, 2, 4, 16, 4)
+    m = _fresh_model()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x, a = util.dev(lrs), util.dev(alphas)
+    target = torch.zeros((2, 1, 48, 48), device="cuda") + 0.1
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = ((m(x, a) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.7 * losses[0], losses
+    with torch.no_grad():
+        after = ((m.eval()(x, a) - target) ** 2).mean()
+    assert float(after) < losses[0]
+
+
+def test_hrnet_backward_rejects_nonpositive_slope():
+    m = _fresh_model()
+    with torch.no_grad():
+        m.decode.deconv[1].weight.fill_(-0.1)
+    lrs, alphas, _ = synth.make_batch(5, 1, 2, 16, 2)
+    with pytest.raises(NotImplementedError):
+        m(util.dev(lrs), util.dev(alphas))
