@@ -49,12 +49,18 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void scalar_finish_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += partial[i];
-        out[0] += (float)s;
+// out[0] += sum of partial[0..n): one 256-thread block, fixed summation tree (deterministic)
+__global__ __launch_bounds__(256) void scalar_finish_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) out[0] += (float)red[0];
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (bias grads)
@@ -75,12 +81,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
         partial[(size_t)blockIdx.x * C + c] = s;
     }
 }
-__global__ void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] += sum over blocks of partial[b][c]: one block per 32 channels, 8 block-phases per channel, fixed order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, ph = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
-    out[c] += (float)s;
+    for (int b = ph; b < nblk; b += 8) s += partial[(size_t)b * C + c];
+    red[ph][cl] = s;
+    __syncthreads();
+    if (ph == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        out[c] += (float)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ dgrad weights
@@ -199,11 +213,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
 // dW[co][ci][tap] (OIHW, full cin/cout) += sum over workgroups of partial[blk][tap][co_l][ci_l]
 __global__ void wgrad_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dw, int cin, int co_chunk,
                                     int ci_chunk) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over 9 * 64 * 64
-    if (idx >= 9 * 4096) return;
-    const int tap = idx / 4096, co_l = (idx >> 6) & 63, ci_l = idx & 63;
+    // block = 64 consecutive elements x 4 workgroup phases (more loads in flight than one thread per element), fixed order
+    __shared__ double red[4][64];
+    const int el = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + el;                       // over 9 * 64 * 64
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * 9 * 4096 + idx];
+    for (int b = ph; b < nblk; b += 4) s += (double)partial[(size_t)b * 9 * 4096 + idx];
+    red[ph][el] = s;
+    __syncthreads();
+    if (ph != 0) return;
+    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    const int tap = idx / 4096, co_l = (idx >> 6) & 63, ci_l = idx & 63;
     const int co = co_chunk * 64 + co_l, ci = ci_chunk * 64 + ci_l;
     dw[((size_t)co * cin + ci) * 9 + tap] += (float)s;
 }
@@ -338,7 +358,7 @@ int hrn_launch_prelu_bwd(const float* dy, const float* y, const float* slope, fl
     double* partial = (double*)scratch;
     const int blocks = RED_BLOCKS;
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, y, slope, g, n / 4, partial);
-    hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, dslope);
+    hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, dslope);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -349,7 +369,7 @@ int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scrat
     const int blocks = RED_BLOCKS;
     if (C == 64) hipLaunchKernelGGL(colsum_kernel<64>, dim3(blocks), dim3(256), 0, s, g, rows, partial);
     else hipLaunchKernelGGL(colsum_kernel<128>, dim3(blocks), dim3(256), 0, s, g, rows, partial);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(128), 0, s, partial, blocks, C, db);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(256), 0, s, partial, blocks, C, db);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -381,7 +401,7 @@ int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int p
         for (int ic = 0; ic < cin / 64; ++ic) {
             p.co_chunk = cc; p.ci_chunk = ic;
             hipLaunchKernelGGL(conv_wgrad_kernel, dim3(grid), dim3(256), WG_LDS, s, p);
-            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((9 * 4096 + 255) / 256), dim3(256), 0, s, (const float*)scratch, grid, dw, cin, cc, ic);
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(9 * 4096 / 64), dim3(256), 0, s, (const float*)scratch, grid, dw, cin, cc, ic);
         }
     HRN_LAUNCH_CHECK();
     return 0;

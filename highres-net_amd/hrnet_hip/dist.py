@@ -3,8 +3,13 @@
 HRNet.forward has no cross-sample operation, so the batch shards over ranks with NO data-path collective:
 every rank runs the same kernels on its own B samples ("replicas"; weak scaling).  torch.distributed (backend
 "nccl" == RCCL on ROCm, "gloo" in the CPU tests) is used only for the rendezvous, the barriers around the timed
-region and the max-over-ranks reduction of the elapsed time.  Gradient all-reduce belongs to the training
-path (row f3) and is not built yet.
+region and the max-over-ranks reduction of the elapsed time.
+
+Training (row f3) adds ONE exchange step per optimisation step: the average of the parameter gradients over ranks
+(`allreduce_gradients`, called between `loss.backward()` and `optimizer.step()`, train.py:190-191).  HRNet has 0.59 M
+parameters (2.4 MB) and ShiftNet 34.2 M (137 MB, almost all of it fc1): gradients are flattened into buckets of
+`bucket_mb` and each bucket is all-reduced once - on xGMI a ring all-reduce is per-link bound (~153 GB/s), so few large
+messages beat many small ones; the first buckets are on the wire while later ones are still being flattened.
 """
 import os
 
@@ -62,6 +67,49 @@ def shard(global_batch, rank, world_size):
         raise ValueError(f"global batch {global_batch} is not divisible by world size {world_size}")
     per = global_batch // world_size
     return rank * per, (rank + 1) * per
+
+
+def allreduce_gradients(modules, bucket_mb=64):
+    """Average `.grad` of every parameter of `modules` (a module or an iterable of modules) over all ranks, in place.
+
+    Identity without a process group.  Parameters are walked in registration order, which is identical on every rank, so
+    the buckets line up; parameters without a gradient on this rank contribute zeros (and receive the average).  Returns
+    the number of bytes reduced (for logging).
+    """
+    if isinstance(modules, torch.nn.Module):
+        modules = [modules]
+    params = [p for m in modules for p in m.parameters() if p.requires_grad]
+    if not dist.is_initialized() or dist.get_world_size() == 1 or not params:
+        return 0
+    ws = dist.get_world_size()
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    limit = int(bucket_mb * (1 << 20))
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nbytes = p.grad.numel() * p.grad.element_size()
+        if cur and (cur_bytes + nbytes > limit or p.grad.dtype != cur[0].grad.dtype or p.grad.device != cur[0].grad.device):
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    pending, total = [], 0
+    for b in buckets:
+        flat = torch.cat([p.grad.reshape(-1) for p in b])
+        total += flat.numel() * flat.element_size()
+        pending.append((b, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)))
+    for b, flat, work in pending:
+        work.wait()
+        flat.div_(ws)
+        off = 0
+        for p in b:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    return total
 
 
 def finalize():

@@ -54,3 +54,45 @@ def test_two_rank_gloo_plumbing(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     assert '"value": 32.0' in outs[0][0]
+
+
+GRAD_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.path.join(%r, "highres-net_amd"))
+    import torch
+    from hrnet_hip import dist as hdist
+    rank, local_rank, ws = hdist.init(backend="gloo")
+    torch.manual_seed(0)                                  # identical parameters on both ranks
+    net = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.PReLU(), torch.nn.Linear(200, 7))
+    other = torch.nn.Linear(5, 5)                         # a second module; its bias gets no gradient on rank 1
+    x = torch.full((4, 300), float(rank + 1))
+    (net(x).sum() + (other.weight.sum() if rank == 1 else other(torch.ones(1, 5)).sum())).backward()
+    local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for m in (net, other) for p in m.parameters()]
+    nbytes = hdist.allreduce_gradients([net, other], bucket_mb=0.1)       # 0.1 MiB buckets: several buckets for 0.25 MB
+    assert nbytes == sum(g.numel() * 4 for g in local), nbytes
+    # reference: gather every rank's local gradients and average them by hand
+    for g, p in zip(local, [p for m in (net, other) for p in m.parameters()]):
+        both = [torch.zeros_like(g) for _ in range(ws)]
+        torch.distributed.all_gather(both, g)
+        want = sum(both) / ws
+        assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7), (p.shape, (p.grad - want).abs().max())
+    hdist.barrier()
+    if rank == 0:
+        print("grads averaged")
+    hdist.finalize()
+""") % ROOT
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    """The one exchange step of data-parallel training: bucketed average of the gradients, here on gloo."""
+    script = tmp_path / "grad_worker.py"
+    script.write_text(GRAD_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    assert "grads averaged" in outs[0][0]
