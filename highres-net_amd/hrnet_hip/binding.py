@@ -71,6 +71,9 @@ SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_lanczos_kernel": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_lanczos_shift": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "hrn_lanczos_shift_backward_workspace_bytes": (_c.c_size_t, [_c.c_int] * 4),
+    "hrn_lanczos_shift_backward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                              _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_get_loss": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_shift_cpsnr_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "hrn_shift_cpsnr": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
@@ -369,6 +372,22 @@ def lanczos_shift(img, shift):
     with torch.cuda.device(img.device):
         _check(lib.hrn_lanczos_shift(_ptr(img), _ptr(shift), b, c, H, W, _ptr(out), _stream()), "hrn_lanczos_shift")
     return out
+
+
+def lanczos_shift_backward(img, shift, d_out, need_img=True, need_shift=True):
+    """Gradients of lanczos_shift(img, shift) given d_out: (d_img or None, d_shift (c, 2) or None)."""
+    lib = load_library()
+    img, shift, d_out = _dev_f32(img, "img"), _dev_f32(shift, "shift"), _dev_f32(d_out, "d_out")
+    b, c, H, W = img.shape
+    nbytes = lib.hrn_lanczos_shift_backward_workspace_bytes(b, c, H, W)
+    ws = _workspace(nbytes, img.device, "lanczos_bwd")
+    d_img = torch.empty_like(img) if need_img else None
+    d_shift = torch.zeros((c, 2), dtype=torch.float32, device=img.device) if need_shift else None
+    with torch.cuda.device(img.device):
+        _check(lib.hrn_lanczos_shift_backward(_ptr(img), _ptr(shift), _ptr(d_out), b, c, H, W,
+                                              _ptr(d_img) if need_img else None, _ptr(d_shift) if need_shift else None,
+                                              _ptr(ws), ws.numel(), _stream()), "hrn_lanczos_shift_backward")
+    return d_img, d_shift
 
 
 # --------------------------------------------------------------------------- built-in kernel timing

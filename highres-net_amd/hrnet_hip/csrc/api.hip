@@ -360,6 +360,19 @@ int hrn_lanczos_shift(const float* img, const float* shift, int b, int c, int H,
 }
 
 // ----------------------------------------------------------------- loss / score reductions
+size_t hrn_lanczos_shift_backward_workspace_bytes(int b, int c, int H, int W) {
+    if (b <= 0 || c <= 0 || H <= 0 || W <= 0) return 0;
+    return hrn_lanczos_bwd_workspace_bytes_impl(b, c, H, W);
+}
+
+int hrn_lanczos_shift_backward(const float* img, const float* shift, const float* d_out, int b, int c, int H, int W, float* d_img,
+                               float* d_shift, void* ws, size_t ws_bytes, void* stream) {
+    HRN_CHECK(img && shift && d_out && ws, -2, "hrn_lanczos_shift_backward: null argument");
+    HRN_CHECK(b > 0 && c > 0, -2, "hrn_lanczos_shift_backward: empty input b=%d c=%d", b, c);
+    HRN_CHECK(ws_bytes >= hrn_lanczos_bwd_workspace_bytes_impl(b, c, H, W), -3, "hrn_lanczos_shift_backward: workspace too small");
+    return hrn_launch_lanczos_shift_bwd(img, shift, d_out, b, c, H, W, d_img, d_shift, ws, (hipStream_t)stream);
+}
+
 int hrn_get_loss(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out, void* stream) {
     HRN_CHECK(B > 0 && S > 0 && crop >= 0 && 2 * crop < S, -2, "hrn_get_loss: bad shape B=%d S=%d crop=%d", B, S, crop);
     HRN_CHECK(metric >= 0 && metric <= 2, -2, "hrn_get_loss: metric must be 0 (masked_MSE), 1 (cMSE) or 2 (cPSNR)");

@@ -20,6 +20,10 @@ int hrn_launch_decoder_pack(int dt, const float* w_iokk, void* packed, hipStream
 // ---- lanczos.hip
 int hrn_launch_lanczos_taps(const float* d, int n, float* taps, hipStream_t stream);
 int hrn_launch_lanczos_shift(const float* img, const float* shift, int b, int c, int H, int W, float* out, hipStream_t stream);
+// ---- lanczos_bwd.hip: d_img (may be null) = adjoint of the shift, d_shift [c][2] (may be null) += gradient through the taps
+size_t hrn_lanczos_bwd_workspace_bytes_impl(int b, int c, int H, int W);
+int hrn_launch_lanczos_shift_bwd(const float* img, const float* shift, const float* dout, int b, int c, int H, int W, float* d_img,
+                                 float* d_shift, void* ws, hipStream_t stream);
 
 // ---- losses.hip
 int hrn_launch_masked_cmse(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out,

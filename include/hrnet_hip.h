@@ -134,6 +134,12 @@ int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* params, 
 int hrn_lanczos_kernel(const float* dx, int n, float* taps, void* stream);
 /* img (b,c,H,W) f32, shift (c,2) = (dy,dx) per channel -> out (b,c,H,W) f32;  a = 3, N = 7, any p >= 3. */
 int hrn_lanczos_shift(const float* img, const float* shift, int b, int c, int H, int W, float* out, void* stream);
+/* Backward of hrn_lanczos_shift (autograd through lanczos.lanczos_shift / ShiftNet.transform in apply_shifts,
+ * src/train.py:47-63, lanczos.py:47-107): d_img (b,c,H,W) = adjoint of the shift applied to d_out (may be NULL),
+ * d_shift (c,2) += gradient through the Lanczos taps, summed over b (may be NULL). */
+size_t hrn_lanczos_shift_backward_workspace_bytes(int b, int c, int H, int W);
+int hrn_lanczos_shift_backward(const float* img, const float* shift, const float* d_out, int b, int c, int H, int W,
+                               float* d_img, float* d_shift, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ loss / score reductions
  * hrn_get_loss     <-  get_loss(srs, hrs, hr_maps, metric)   src/train.py:66-87, with get_crop_mask (:90-106) folded in:

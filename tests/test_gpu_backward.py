@@ -98,3 +98,49 @@ def test_hrnet_backward_rejects_nonpositive_slope():
     lrs, alphas, _ = synth.make_batch(5, 1, 2, 16, 2)
     with pytest.raises(NotImplementedError):
         m(util.dev(lrs), util.dev(alphas))
+
+
+# ----------------------------------------------------------------------------- Lanczos shift backward
+def _torch_lanczos_shift(img, shift):
+    """fp64 torch restatement of lanczos.py:5-107 (reflect pad 3, vertical then horizontal 7-tap correlation per channel)."""
+    import math
+    import torch.nn.functional as F
+    c = img.shape[1]
+
+    def taps(d):
+        x = torch.linspace(-3, 3, 7, dtype=d.dtype).view(1, -1) - d.view(-1, 1)
+        t = math.pi * x
+        t = torch.where(t == 0, torch.tensor(1e-6, dtype=d.dtype), t)
+        k = torch.sin(t) / t * torch.sin(t / 3) / (t / 3)
+        return k / k.sum(1, keepdim=True)
+
+    ky, kx = taps(shift[:, 0]), taps(shift[:, 1])
+    pad = F.pad(img, (3, 3, 3, 3), mode="reflect")
+    out = F.conv2d(pad, ky.view(c, 1, 7, 1), groups=c)
+    return F.conv2d(out, kx.view(c, 1, 1, 7), groups=c)
+
+
+@pytest.mark.parametrize("b,c,H,W", [(1, 5, 48, 48), (2, 3, 20, 70), (1, 2, 7, 9)])
+def test_lanczos_shift_backward_vs_autograd(b, c, H, W):
+    import lanczos
+    rng = np.random.Generator(np.random.PCG64(11))
+    img = rng.random((b, c, H, W), dtype=np.float32)
+    shift = rng.uniform(-1.5, 1.5, (c, 2)).astype(np.float32)
+    shift[0] = (0.0, 0.25)                                   # an exact-zero shift: pi*x == 0 at the centre tap (frozen to 1e-6)
+    cot = rng.standard_normal((b, c, H, W)).astype(np.float32)
+    ti = torch.from_numpy(img).double().requires_grad_(True)
+    ts = torch.from_numpy(shift).double().requires_grad_(True)
+    want = _torch_lanczos_shift(ti, ts)
+    (want * torch.from_numpy(cot).double()).sum().backward()
+    gi = util.dev(img).requires_grad_(True)
+    gs = util.dev(shift).requires_grad_(True)
+    got = lanczos.lanczos_shift(gi, gs)
+    assert got.requires_grad
+    assert np.abs(got.detach().cpu().numpy() - want.detach().numpy()).max() <= 2e-5
+    (got * util.dev(cot)).sum().backward()
+    assert util.rel_err(gi.grad.cpu().numpy(), ti.grad.numpy()) <= 1e-4
+    assert np.abs(gs.grad.cpu().numpy() - ts.grad.numpy()).max() <= 1e-3 * max(1.0, float(ts.grad.abs().max()))
+    # image-only and shift-only requests
+    gi2 = util.dev(img).requires_grad_(True)
+    (lanczos.lanczos_shift(gi2, util.dev(shift)) * util.dev(cot)).sum().backward()
+    assert util.rel_err(gi2.grad.cpu().numpy(), ti.grad.numpy()) <= 1e-4
