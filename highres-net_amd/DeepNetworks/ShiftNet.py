@@ -12,6 +12,33 @@ import lanczos
 from hrnet_hip import binding
 
 
+class _ShiftNetTrainFunction(torch.autograd.Function):
+    """`shifts = regis_model(pairs)` ... `loss.backward()` (train.py:40, :190) on the HIP kernels: hrn_shiftnet_forward_train
+    keeps each layer's pre-BatchNorm tensor and batch statistics; hrn_shiftnet_backward returns the gradients of every
+    parameter and of the input pairs (the SR crops come from HRNet, so the registration loss trains it too)."""
+
+    @staticmethod
+    def forward(ctx, module, names, mask, x, *params):
+        named = module._named()
+        theta, tws = binding.shiftnet_forward_train(module.packed_parameters(), named, x.detach(), momentum=module.layer1[1].momentum,
+                                                    dropout_mask=mask)
+        ctx.module, ctx.names, ctx.mask, ctx.tws = module, names, mask, tws
+        ctx.save_for_backward(x, *params)
+        return theta
+
+    @staticmethod
+    def backward(ctx, d_theta):
+        x, *params = ctx.saved_tensors
+        named = ctx.module._named()
+        for k, p in zip(ctx.names, params):
+            named[k] = p
+        grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in zip(ctx.names, params)}
+        d_x = binding.shiftnet_backward(named, grads, x.detach(), ctx.mask, d_theta.contiguous(), ctx.tws,
+                                        need_input_grad=ctx.needs_input_grad[3])
+        ctx.tws = None
+        return (None, None, None, d_x) + tuple(grads[k] for k in ctx.names)
+
+
 class ShiftNet(nn.Module):
     def __init__(self, in_channel=1):
         super().__init__()
@@ -46,15 +73,19 @@ class ShiftNet(nn.Module):
 
     def forward(self, x):
         """x (B, 2, 128, 128) pairs (reference, image) -> (B, 2) translations (dx, dy)."""
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "backward kernels are not built yet (SURVEY.md section 8 row f3): call under torch.no_grad()")
         mask = None
         if self.training and self.drop1.p > 0:
             if self.drop1.p != 0.5:
                 raise NotImplementedError("dropout p must be 0.5 (reference ShiftNet.py:43)")
             mask = (torch.rand((x.shape[0], 32768), device=x.device) >= 0.5).to(torch.uint8)
         named = self._named()
+        if self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training path: train-mode forward that keeps its intermediates + the HIP backward (parameters and input pairs)
+            names = [k for k, _ in self.named_parameters()]
+            theta = _ShiftNetTrainFunction.apply(self, names, mask, x, *[p for _, p in self.named_parameters()])
+            for i in range(1, 9):
+                getattr(self, f"layer{i}")[1].num_batches_tracked += 1
+            return theta
         theta = binding.shiftnet_forward(self.packed_parameters(), named, x.detach(), train_bn=self.training,
                                          momentum=self.layer1[1].momentum, dropout_mask=mask)
         if self.training:

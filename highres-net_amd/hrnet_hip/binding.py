@@ -69,6 +69,11 @@ SIGNATURES = {
     "hrn_shiftnet_workspace_bytes": (_c.c_size_t, [_c.c_int]),
     "hrn_shiftnet_forward": (_c.c_int, [_c.c_void_p, _c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_int, _c.c_int, _c.c_float,
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_shiftnet_train_workspace_bytes": (_c.c_size_t, [_c.c_int]),
+    "hrn_shiftnet_forward_train": (_c.c_int, [_c.c_void_p, _c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_int, _c.c_float, _c.c_void_p,
+                                              _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_shiftnet_backward": (_c.c_int, [_c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                         _c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_lanczos_kernel": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_lanczos_shift": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_lanczos_shift_backward_workspace_bytes": (_c.c_size_t, [_c.c_int] * 4),
@@ -348,6 +353,56 @@ def shiftnet_forward(packed, named, x, train_bn=False, momentum=0.1, dropout_mas
         _check(lib.hrn_shiftnet_forward(_ptr(packed), ctypes.byref(P), _ptr(x), B, int(bool(train_bn)), float(momentum), mptr,
                                         _ptr(theta), _ptr(ws), ws.numel(), _stream()), "hrn_shiftnet_forward")
     return theta
+
+
+def _check_shiftnet_input(x, dropout_mask):
+    if x.dim() != 4 or tuple(x.shape[1:]) != (2, 128, 128):
+        raise ValueError(f"ShiftNet input must be (B,2,128,128) (fc1 is hard-wired to 128*16*16, ShiftNet.py:44); got {tuple(x.shape)}")
+    B = x.shape[0]
+    if dropout_mask is None:
+        return ctypes.c_void_p(0), None
+    if dropout_mask.dtype != torch.uint8 or tuple(dropout_mask.shape) != (B, 32768) or not dropout_mask.is_cuda:
+        raise ValueError("dropout_mask must be a uint8 device tensor of shape (B, 32768)")
+    dropout_mask = dropout_mask.contiguous()
+    return _ptr(dropout_mask), dropout_mask
+
+
+def shiftnet_forward_train(packed, named, x, momentum=0.1, dropout_mask=None):
+    """Train-mode forward that keeps its intermediates: returns (theta (B,2), train_ws)."""
+    lib = load_library()
+    x = _dev_f32(x, "x")
+    mptr, dropout_mask = _check_shiftnet_input(x, dropout_mask)
+    B = x.shape[0]
+    keep = []
+    P = _shiftnet_struct(named, keep, False)
+    nbytes = lib.hrn_shiftnet_train_workspace_bytes(B)
+    tws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    theta = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.hrn_shiftnet_forward_train(_ptr(packed), ctypes.byref(P), _ptr(x), B, float(momentum), mptr, _ptr(theta),
+                                              _ptr(tws), nbytes, _stream()), "hrn_shiftnet_forward_train")
+    return theta, tws
+
+
+def shiftnet_backward(named, named_grads, x, dropout_mask, d_theta, tws, need_input_grad=True):
+    """Accumulates the parameter gradients into named_grads (parameter keys only); returns d_x (B,2,128,128) or None."""
+    lib = load_library()
+    x = _dev_f32(x, "x")
+    d_theta = _dev_f32(d_theta, "d_theta")
+    mptr, dropout_mask = _check_shiftnet_input(x, dropout_mask)
+    B = x.shape[0]
+    keep = []
+    P = _shiftnet_struct(named, keep, True)
+    gfull = dict(named_grads)
+    for k, v in named.items():                               # the struct builder also wants the (unused) running stats
+        gfull.setdefault(k, v)
+    G = _shiftnet_struct(gfull, keep, True)
+    d_x = torch.empty_like(x) if need_input_grad else None
+    with torch.cuda.device(x.device):
+        _check(lib.hrn_shiftnet_backward(ctypes.byref(P), _ptr(x), B, mptr, _ptr(d_theta), ctypes.byref(G),
+                                         _ptr(d_x) if need_input_grad else None, _ptr(tws), tws.numel(), _stream()),
+               "hrn_shiftnet_backward")
+    return d_x
 
 
 # --------------------------------------------------------------------------- Lanczos

@@ -3,6 +3,7 @@
 #include "../../../include/hrnet_hip.h"
 #include "kernels.h"
 #include "hrnet_layout.h"
+#include "shiftnet_layout.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -124,24 +125,7 @@ int decoder_impl(const void* pk, int dt, int nl, const void* fused, int N, int H
                               (const float*)at(pk, L.fin_w), (const float*)at(pk, L.fin_b), sr, N, H, W, s);
 }
 
-// ---------------------------------------------------------------- ShiftNet layouts
-const int SN_CI[8] = {2, 64, 64, 64, 64, 128, 128, 128};
-const int SN_CO[8] = {64, 64, 64, 64, 128, 128, 128, 128};
-const int SN_POOL[8] = {0, 1, 0, 1, 0, 1, 0, 0};
-constexpr int SN_PARTIAL_BLOCKS = 256;
-
-struct SnLayout {
-    size_t conv_w[8], conv_b[8], fc1_w, fc1_b, fc2_w, total;
-};
-SnLayout sn_layout() {
-    SnLayout L;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = hrn_align_up(off + bytes, ALIGN); return o; };
-    for (int i = 0; i < 8; ++i) { L.conv_w[i] = take((size_t)SN_CI[i] * SN_CO[i] * 9 * 4); L.conv_b[i] = take(SN_CO[i] * 4); }
-    L.fc1_w = take((size_t)1024 * 32768 * 4); L.fc1_b = take(1024 * 4); L.fc2_w = take(2 * 1024 * 4);
-    L.total = off;
-    return L;
-}
+// ---------------------------------------------------------------- ShiftNet layouts (packed parameters: shiftnet_layout.h)
 struct SnWs {
     size_t means, scale, shift, partial, x, y, fc, total;
 };

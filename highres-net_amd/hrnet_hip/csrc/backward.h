@@ -19,6 +19,9 @@ int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int p
 // stem 2 -> 64: in0 = image m (stride0 floats apart), in1 = plane m / rep1; dw [64][2][3][3]
 int hrn_launch_stem_wgrad(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* g, int M, int H,
                           int W, float* dw, void* scratch, int num_cus, hipStream_t s);
+// the same with `sub` [M][2] subtracted from the in-image pixels of the two planes first (ShiftNet's mean-free input)
+int hrn_launch_stem_wgrad_sub(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* sub,
+                              const float* g, int M, int H, int W, float* dw, void* scratch, int num_cus, hipStream_t s);
 int hrn_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t s);
 // fusion level helpers (HRNet.py:113-132): forward update of the kept views, and the two backward maps
 int hrn_launch_fuse_update(const float* stack, int n_in, const float* f, const float* alphas, int alpha_vs, int pair_last, int half,
@@ -33,3 +36,8 @@ int hrn_launch_decoder_bwd(const float* fused, const float* d_sr, const float* w
                            float* d_fused, float* dwd, float* dbd, float* dad, float* dwf, float* dbf, int N, int H, int W,
                            void* scratch, int num_cus, hipStream_t s);
 size_t hrn_decoder_bwd_scratch_bytes(int num_cus);
+// dx = conv3x3(g, W^T with taps flipped) (+ res): the data gradient of a cin -> cout convolution with raw weights
+// w [cout][cin][3][3], on the forward f32 kernel.  wt / wtp: scratch for the transposed OIHW tensor and its packed form
+// (cin*cout*9 floats each); zero_bias: max(cin, cout) zero floats.
+int hrn_conv_dgrad(int cin, int cout, const float* w, const float* g, float* dx, const float* res, int M, int H, int W, float* wt,
+                   void* wtp, const float* zero_bias, hipStream_t s);

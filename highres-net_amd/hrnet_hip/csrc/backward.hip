@@ -231,8 +231,8 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ partial, int nblk,
 // ------------------------------------------------------------------------------------------------ stem weight gradient
 // dW[co][c2][tap] += sum g[m][p][co] * in_c2[m][p + tap], in_0 = view m, in_1 = reference frame of sample m / rep1
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ in0, size_t stride0, const float* __restrict__ in1,
-                                                         int rep1, size_t stride1, const float* __restrict__ g, int M, int H, int W,
-                                                         float* __restrict__ partial) {
+                                                         int rep1, size_t stride1, const float* __restrict__ sub,
+                                                         const float* __restrict__ g, int M, int H, int W, float* __restrict__ partial) {
     __shared__ float tile[2][WG_HH][WG_HW];
     const int tid = threadIdx.x, co = tid & 63, q = tid >> 6;
     const int tiles_x = (W + WG_TW - 1) / WG_TW, tiles_y = (H + WG_TH - 1) / WG_TH;
@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             const int py = pix / WG_HW, px = pix - py * WG_HW;
             const int gy = y0 + py - 1, gx = x0 + px - 1;
             float v = 0.f;
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = (c == 0 ? p0 : p1)[(size_t)gy * W + gx];
+            // `sub` (ShiftNet): the forward subtracts the plane mean before the zero padding, ShiftNet.py:58
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = (c == 0 ? p0 : p1)[(size_t)gy * W + gx] - (sub ? sub[m * 2 + c] : 0.f);
             tile[c][py][px] = v;
         }
         __syncthreads();
@@ -409,10 +410,15 @@ int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int p
 
 int hrn_launch_stem_wgrad(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* g, int M, int H,
                           int W, float* dw, void* scratch, int num_cus, hipStream_t s) {
+    return hrn_launch_stem_wgrad_sub(in0, stride0, in1, rep1, stride1, nullptr, g, M, H, W, dw, scratch, num_cus, s);
+}
+
+int hrn_launch_stem_wgrad_sub(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* sub,
+                              const float* g, int M, int H, int W, float* dw, void* scratch, int num_cus, hipStream_t s) {
     const long tiles = (long)((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * M;
     int grid = num_cus;
     if (tiles < grid) grid = (int)tiles;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, g, M, H, W, (float*)scratch);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, sub, g, M, H, W, (float*)scratch);
     hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3((64 * 18 + 255) / 256), dim3(256), 0, s, (const float*)scratch, grid * 4, dw);
     HRN_LAUNCH_CHECK();
     return 0;
@@ -449,4 +455,16 @@ int hrn_launch_fuse_scatter(const float* dsn, const float* dz, int n_in, int hal
                        alpha_residual, ds, hw, B);
     HRN_LAUNCH_CHECK();
     return 0;
+}
+
+int hrn_conv_dgrad(int cin, int cout, const float* w, const float* g, float* dx, const float* res, int M, int H, int W, float* wt,
+                   void* wtp, const float* zero_bias, hipStream_t s) {
+    int rc;
+    if ((rc = hrn_launch_dgrad_weights(w, wt, cin, cout, s))) return rc;
+    if ((rc = hrn_launch_conv_pack(HRN_F32, cout, cin, wt, wtp, s))) return rc;           // a cout -> cin convolution
+    ConvParams p = ConvParams();
+    p.M = M; p.H = H; p.W = W;
+    p.in = g; p.out = dx; p.wpk = wtp; p.bias = zero_bias; p.slope = nullptr;
+    if (res) { p.res = res; p.res_mode = 1; }
+    return hrn_launch_conv3x3(HRN_F32, cout, cin, p, s);
 }

@@ -93,15 +93,7 @@ int conv_fwd(int cin, int cout, const void* x, void* y, const void* wpk, const f
 // dx = conv3x3(g, W^T flipped) (+ res): the data gradient of a cin -> cout convolution with raw weights w [cout][cin][3][3]
 int conv_dgrad(int cin, int cout, const float* w, const float* g, float* dx, const float* res, int M, int H, int W, void* tws,
                const TrainWs& L, hipStream_t s) {
-    int rc;
-    float* wt = (float*)at(tws, L.wt);
-    void* wtp = at(tws, L.wtp);
-    if ((rc = hrn_launch_dgrad_weights(w, wt, cin, cout, s))) return rc;
-    if ((rc = hrn_launch_conv_pack(HRN_F32, cout, cin, wt, wtp, s))) return rc;           // a cout -> cin convolution
-    ConvParams p = conv_base(M, H, W);
-    p.in = g; p.out = dx; p.wpk = wtp; p.bias = (const float*)at(tws, L.zero_bias); p.slope = nullptr;
-    if (res) { p.res = res; p.res_mode = 1; }
-    return hrn_launch_conv3x3(HRN_F32, cout, cin, p, s);
+    return hrn_conv_dgrad(cin, cout, w, g, dx, res, M, H, W, (float*)at(tws, L.wt), at(tws, L.wtp), (const float*)at(tws, L.zero_bias), s);
 }
 
 // z + u for the pair gather z of a level: t2[b*half + i][p][c] = (c < 64 ? s_i : s_partner)[p][c % 64] + u[...]
@@ -189,7 +181,6 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
     if ((rc = check_train(nl, B, V, H, W))) return rc;
     const TrainWs L = train_ws(nl, B, V, H, W);
     HRN_CHECK(tws_bytes >= L.total, -3, "hrn_hrnet_backward: workspace too small (%zu < %zu)", tws_bytes, L.total);
-    const HrnetLayout P = hrnet_layout(HRN_F32, nl);
     hipStream_t s = (hipStream_t)stream;
     const size_t hw = (size_t)H * W;
     const int M = B * V, cus = num_cus();

@@ -129,6 +129,20 @@ int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* params, 
                          int train_bn, float momentum, const unsigned char* dropout_mask, float* theta,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Training path (ShiftNet in .train() mode; `shifts = register_batch(regis_model, ...)` ... `loss.backward()`,
+ * src/train.py:176-190).  hrn_shiftnet_forward_train = hrn_shiftnet_forward(train_bn = 1) with every layer's tensors
+ * and batch statistics kept in `train_ws`; hrn_shiftnet_backward turns d_theta (B,2) into the parameter gradients,
+ * ACCUMULATED (+=) into the buffers of `grads` (conv_w/conv_b/bn_g/bn_b/fc1_w/fc1_b/fc2_w in the parameters' own
+ * reference layouts; bn_rm/bn_rv are not read), and, when d_x is not NULL, writes the gradient of the input pairs
+ * d_x (B,2,128,128).  `params` are the raw reference-layout tensors, `dropout_mask` the mask the forward used.  B <= 32. */
+size_t hrn_shiftnet_train_workspace_bytes(int B);
+int hrn_shiftnet_forward_train(const void* packed, const hrn_shiftnet_params* params, const float* x, int B, float momentum,
+                               const unsigned char* dropout_mask, float* theta, void* train_ws, size_t train_ws_bytes,
+                               void* stream);
+int hrn_shiftnet_backward(const hrn_shiftnet_params* params, const float* x, int B, const unsigned char* dropout_mask,
+                          const float* d_theta, const hrn_shiftnet_params* grads, float* d_x, void* train_ws,
+                          size_t train_ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ Lanczos */
 /* dx (n) f32 -> taps (n,7) f32;  a = 3, N = 7 (the only values the reference's call sites use). */
 int hrn_lanczos_kernel(const float* dx, int n, float* taps, void* stream);

@@ -144,3 +144,144 @@ def test_lanczos_shift_backward_vs_autograd(b, c, H, W):
     gi2 = util.dev(img).requires_grad_(True)
     (lanczos.lanczos_shift(gi2, util.dev(shift)) * util.dev(cot)).sum().backward()
     assert util.rel_err(gi2.grad.cpu().numpy(), ti.grad.numpy()) <= 1e-4
+
+
+# ----------------------------------------------------------------------------- ShiftNet backward
+def _torch_shiftnet(x, st, mask):
+    """fp64 torch restatement of ShiftNet.forward in train mode (ShiftNet.py:49-75) with a given dropout keep-mask."""
+    import torch.nn.functional as F
+    x = x - x.mean(dim=(2, 3), keepdim=True)
+    for i in range(1, 9):
+        x = F.conv2d(x, st[f"layer{i}.0.weight"], st[f"layer{i}.0.bias"], padding=1)
+        x = F.batch_norm(x, None, None, st[f"layer{i}.1.weight"], st[f"layer{i}.1.bias"], training=True, eps=1e-5)
+        x = F.relu(x)
+        if i in (2, 4, 6):
+            x = F.max_pool2d(x, 2)
+    x = x.reshape(x.shape[0], -1) * mask * 2.0
+    x = F.relu(F.linear(x, st["fc1.weight"], st["fc1.bias"]))
+    return F.linear(x, st["fc2.weight"])
+
+
+def test_shiftnet_backward_vs_autograd():
+    from DeepNetworks.ShiftNet import ShiftNet
+    B = 3
+    rng = np.random.Generator(np.random.PCG64(21))
+    x = (rng.random((B, 2, 128, 128), dtype=np.float32) * 0.25).astype(np.float32)
+    x[:, 1] = 0.7 * x[:, 0] + 0.3 * x[:, 1]                  # correlated pair, like (reference, image)
+    mask = (rng.random((B, 32768)) >= 0.5)
+    cot = rng.standard_normal((B, 2)).astype(np.float32)
+    state = weights.to_torch_state(weights.shiftnet_state(4321))
+    st = {k: v.double().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k) for k, v in state.items()}
+    tx = torch.from_numpy(x).double().requires_grad_(True)
+    want = _torch_shiftnet(tx, st, torch.from_numpy(mask).double())
+    (want * torch.from_numpy(cot).double()).sum().backward()
+
+    m = ShiftNet()
+    m.load_state_dict(state)
+    m = m.cuda().train()
+    gx = util.dev(x).requires_grad_(True)
+    torch.manual_seed(0)
+    # feed the same keep-mask the oracle used: patch the module's RNG draw
+    dmask = torch.from_numpy(mask.astype(np.uint8)).cuda()
+    orig_rand = torch.rand
+    try:
+        torch.rand = lambda *a, **k: (dmask.float() * 0.75 + 0.125).reshape(a[0]) if a and tuple(a[0]) == (B, 32768) else orig_rand(*a, **k)
+        theta = m(gx)
+    finally:
+        torch.rand = orig_rand
+    assert theta.requires_grad
+    assert util.rel_err(theta.detach().cpu().numpy(), want.detach().numpy()) <= 2e-4
+    (theta * util.dev(cot)).sum().backward()
+    assert util.rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) <= 2e-3
+    for k, p in m.named_parameters():
+        got, ref = p.grad.cpu().numpy(), st[k].grad.numpy()
+        if k.endswith(".0.bias"):
+            # a conv bias in front of a train-mode BatchNorm has a mathematically zero gradient: both sides hold rounding noise
+            scale = float(np.abs(st[k.replace(".0.bias", ".1.bias")].grad.numpy()).max())
+            assert np.abs(got).max() <= 1e-3 * scale and np.abs(ref).max() <= 1e-3 * scale, k
+            continue
+        assert util.rel_err(got, ref) <= 2e-3, (k, util.rel_err(got, ref))
+
+
+# ----------------------------------------------------------------------------- the whole train step of src/train.py
+def _register_batch(shiftNet, lrs, reference):                 # train.py:26-44, restated
+    thetas = [shiftNet(torch.cat([reference, lrs[:, i:i + 1]], 1)) for i in range(lrs.size(1))]
+    return torch.stack(thetas, 1)
+
+
+def _get_loss_cpsnr(srs, hrs, hr_maps):                        # train.py:66-87, metric='cPSNR'
+    nclear = torch.sum(hr_maps, dim=(1, 2))
+    bright = torch.sum(hr_maps * (hrs - srs), dim=(1, 2)).clone().detach() / nclear
+    loss = torch.sum(hr_maps * (srs + bright.view(-1, 1, 1) - hrs) ** 2, dim=(1, 2)) / nclear
+    return -10 * torch.log10(loss)
+
+
+def test_full_train_step_vs_autograd_oracle():
+    """srs = fusion_model(lrs, alphas); shifts = register_batch(...); srs_shifted = apply_shifts(...); loss = -cPSNR + lambda
+    mean(shifts)^2; loss.backward()  (train.py:172-190) on the HIP modules, against the same chain in fp64 torch on the CPU."""
+    from DeepNetworks.ShiftNet import ShiftNet
+    B, V, S, lam = 2, 3, 48, 1e-6
+    lrs, alphas, hrs = synth.make_batch(31, B, V, S, V)
+    rng = np.random.Generator(np.random.PCG64(5))
+    maps = (rng.random((B, 3 * S, 3 * S)) > 0.1).astype(np.float32)
+    crop = np.ones((3 * S, 3 * S), np.float32)
+    crop[:3] = 0; crop[-3:] = 0; crop[:, :3] = 0; crop[:, -3:] = 0
+    mask = (rng.random((B, 32768)) >= 0.5)
+    off = (3 * S - 128) // 2
+    hstate = weights.to_torch_state(weights.hrnet_state(1234))
+    sstate = weights.to_torch_state(weights.shiftnet_state(4321))
+
+    # ---- oracle chain, fp64 on the CPU
+    hst = {k: v.double().requires_grad_(True) for k, v in hstate.items()}
+    sst = {k: v.double().requires_grad_("running" not in k and "num_batches" not in k) for k, v in sstate.items()}
+    with torch.enable_grad():
+        srs = torch_port.hrnet_forward.__wrapped__(torch.from_numpy(lrs).double(), torch.from_numpy(alphas).double(), hst,
+                                                  num_layers=weights.HRNET_CONFIG["encoder"]["num_layers"], alpha_residual=True)
+        t_hrs = torch.from_numpy(hrs).double()
+        net = lambda pairs: _torch_shiftnet(pairs, sst, torch.from_numpy(mask).double())
+        shifts = _register_batch(net, srs[:, :, off:off + 128, off:off + 128], t_hrs[:, off:off + 128, off:off + 128].reshape(-1, 1, 128, 128))
+        imgs = srs.view(-1, 1, 3 * S, 3 * S)
+        shifted = _torch_lanczos_shift(imgs.transpose(0, 1), shifts.view(-1, 2).flip(-1))[:, None].view(-1, 1, 3 * S, 3 * S)[:, 0]
+        loss = -_get_loss_cpsnr(shifted, t_hrs, torch.from_numpy(crop * maps).double())
+        loss = loss.mean() + lam * shifts.mean() ** 2
+        loss.backward()
+    want_loss = float(loss.detach())
+
+    # ---- HIP modules, the statements of train.py
+    fusion = _fresh_model(True)
+    regis = ShiftNet()
+    regis.load_state_dict(sstate)
+    regis = regis.cuda().train()
+    d_lrs, d_alphas, d_hrs = util.dev(lrs), util.dev(alphas), util.dev(hrs)
+    dmask = torch.from_numpy(mask.astype(np.uint8)).cuda()
+    orig_rand = torch.rand
+    try:
+        torch.rand = lambda *a, **k: (dmask.float() * 0.75 + 0.125).reshape(a[0]) if a and tuple(a[0]) == (B, 32768) else orig_rand(*a, **k)
+        g_srs = fusion(d_lrs, d_alphas)
+        g_shifts = _register_batch(regis, g_srs[:, :, off:off + 128, off:off + 128],
+                                   d_hrs[:, off:off + 128, off:off + 128].reshape(-1, 1, 128, 128))
+        bsz, nv, hh, ww = g_srs.shape                          # apply_shifts, train.py:47-63
+        g_shifted = regis.transform(g_shifts.view(-1, 2), g_srs.view(-1, 1, hh, ww), device="cuda").view(-1, nv, hh, ww)[:, 0]
+    finally:
+        torch.rand = orig_rand
+    g_loss = -_get_loss_cpsnr(g_shifted, d_hrs, util.dev(crop * maps))
+    g_loss = g_loss.mean() + lam * g_shifts.mean() ** 2
+    g_loss.backward()
+    assert abs(float(g_loss.detach()) - want_loss) <= 2e-4 * abs(want_loss)
+    assert util.rel_err(g_shifts.detach().cpu().numpy(), shifts.detach().numpy()) <= 1e-3
+    # Conditioning: through -10 log10(cMSE) with the brightness correction this chain is ill-conditioned in fp32 - torch's own
+    # fp32 CPU autograd differs from the fp64 value by 3e-3..7e-3 on most tensors here (1.5e-2 on one PReLU slope; measured
+    # with the same ports), and gradients that are zero by construction (decode.final.bias under the brightness correction,
+    # conv biases in front of train-mode BatchNorm) are pure rounding noise on both sides.  Hence 2e-2 / the skips below.
+    for name, model, st in (("hrnet", fusion, hst), ("shiftnet", regis, sst)):
+        scalar_scale = max([float(np.abs(st[k].grad.numpy()).max()) for k, p in model.named_parameters()
+                            if p.numel() == 1 and k != "decode.final.bias"] or [1.0])
+        for k, p in model.named_parameters():
+            assert p.grad is not None, (name, k)
+            got, ref = p.grad.cpu().numpy(), st[k].grad.numpy()
+            if k == "decode.final.bias" or (name == "shiftnet" and k.endswith(".0.bias")):
+                continue
+            if p.numel() == 1:
+                assert abs(float(got.ravel()[0]) - float(ref.ravel()[0])) <= 2e-2 * scalar_scale, (name, k, got, ref)
+            else:
+                assert util.rel_err(got, ref) <= 2e-2, (name, k, util.rel_err(got, ref))
