@@ -125,7 +125,7 @@ class HRNet(nn.Module):
     def packed_parameters(self):
         dt = self._dtype()
         named = dict(self.named_parameters())
-        key = (dt,) + tuple((p.data_ptr(), p._version) for p in named.values())
+        key = (dt, binding.param_epoch) + tuple((p.data_ptr(), p._version) for p in named.values())
         if self._packed is None or self._packed_key != key:
             self._packed = binding.hrnet_pack(named, self._num_layers, dt)
             self._packed_key = key
@@ -148,7 +148,7 @@ class HRNet(nn.Module):
 
     def _packed_f32(self):
         named = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version) for p in named.values())
+        key = (binding.param_epoch,) + tuple((p.data_ptr(), p._version) for p in named.values())
         if getattr(self, "_packed32", None) is None or self._packed32_key != key:
             slopes = torch.stack([p.detach().reshape(()) for k, p in named.items() if p.numel() == 1 and k.endswith(".weight")
                                   and ("block.1" in k or "block.3" in k or k.endswith("init_layer.1.weight")

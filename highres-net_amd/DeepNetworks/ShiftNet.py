@@ -65,7 +65,7 @@ class ShiftNet(nn.Module):
 
     def packed_parameters(self):
         named = dict(self.named_parameters())
-        key = tuple((k, p.data_ptr(), p._version) for k, p in named.items() if ".1." not in k)   # BN tensors are read live
+        key = (binding.param_epoch,) + tuple((k, p.data_ptr(), p._version) for k, p in named.items() if ".1." not in k)   # BN tensors are read live
         if self._packed is None or self._packed_key != key:
             self._packed = binding.shiftnet_pack(self._named())
             self._packed_key = key

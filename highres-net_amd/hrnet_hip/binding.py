@@ -74,6 +74,8 @@ SIGNATURES = {
                                               _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_shiftnet_backward": (_c.c_int, [_c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
                                          _c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_adam_step": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_float, _c.c_float, _c.c_float,
+                                 _c.c_float, _c.c_float, _c.c_int, _c.c_void_p]),
     "hrn_lanczos_kernel": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_lanczos_shift": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_lanczos_shift_backward_workspace_bytes": (_c.c_size_t, [_c.c_int] * 4),
@@ -443,6 +445,29 @@ def lanczos_shift_backward(img, shift, d_out, need_img=True, need_shift=True):
                                               _ptr(d_img) if need_img else None, _ptr(d_shift) if need_shift else None,
                                               _ptr(ws), ws.numel(), _stream()), "hrn_lanczos_shift_backward")
     return d_img, d_shift
+
+
+# --------------------------------------------------------------------------- optimiser
+# Bumped by anything that rewrites parameter storage without going through torch's version counters (the fused Adam
+# kernel writes the flat buffer the parameters are views of); the modules' packed-parameter caches key on it.
+param_epoch = 0
+
+
+def bump_param_epoch():
+    global param_epoch
+    param_epoch += 1
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    """In-place Adam update of the flat fp32 device buffer `params` (torch.optim.Adam arithmetic, no amsgrad)."""
+    lib = load_library()
+    for name, t in (("params", params), ("grads", grads), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == params.numel()):
+            raise ValueError(f"{name} must be a contiguous float32 device tensor of {params.numel()} elements")
+    with torch.cuda.device(params.device):
+        _check(lib.hrn_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), float(lr), float(beta1),
+                                 float(beta2), float(eps), float(weight_decay), int(step), _stream()), "hrn_adam_step")
+    bump_param_epoch()
 
 
 # --------------------------------------------------------------------------- built-in kernel timing

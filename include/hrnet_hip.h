@@ -168,6 +168,14 @@ size_t hrn_shift_cpsnr_workspace_bytes(int B, int border);
 int hrn_shift_cpsnr(const float* srs, const float* hrs, const float* hr_maps, int B, int S, int border, int clip, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ optimiser
+ * hrn_adam_step  <-  optimizer.step() of torch.optim.Adam (src/train.py:191, :252), one launch over a flat fp32 buffer
+ *                    holding every parameter of both models (the buffer the gradient all-reduce also works on):
+ *                    g += weight_decay p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *                    p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).  step counts from 1. */
+int hrn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* ------------------------------------------------------------------ built-in kernel timing (hipEvent pairs)
  * The reference has no profiling hooks; these exist so that bench.py can state, live, the
  * achieved TFLOP/s / GB/s of each kernel family against the gfx950 roofline.  enable(1) clears the table and starts

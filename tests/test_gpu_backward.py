@@ -285,3 +285,47 @@ def test_full_train_step_vs_autograd_oracle():
                 assert abs(float(got.ravel()[0]) - float(ref.ravel()[0])) <= 2e-2 * scalar_scale, (name, k, got, ref)
             else:
                 assert util.rel_err(got, ref) <= 2e-2, (name, k, util.rel_err(got, ref))
+
+
+# ----------------------------------------------------------------------------- fused Adam
+def test_fused_adam_matches_torch_adam():
+    """hrn_adam_step on one flat buffer == torch.optim.Adam tensor by tensor (train.py:252), incl. an lr change by a
+    scheduler through param_groups and weight decay; the HIP modules see the updated weights (packed-cache epoch)."""
+    from hrnet_hip.optim import FusedAdam
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.PReLU(), torch.nn.Linear(19, 5)).cuda()
+    new = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.PReLU(), torch.nn.Linear(19, 5)).cuda()
+    new.load_state_dict(ref.state_dict())
+    o_ref = torch.optim.Adam(ref.parameters(), lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    o_new = FusedAdam(new.parameters(), lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(o_new, mode="max", factor=0.5, patience=0)
+    x = torch.randn(11, 37, device="cuda")
+    for it in range(6):
+        for m, o in ((ref, o_ref), (new, o_new)):
+            o.zero_grad()
+            (m(x) ** 2).mean().backward()
+            o.step()
+        if it == 2:                                       # a plateau: the scheduler halves the lr of the fused optimiser
+            sched.step(1.0); sched.step(0.5)
+            for g in o_ref.param_groups:
+                g["lr"] = o_new.param_groups[0]["lr"]
+            assert o_new.param_groups[0]["lr"] == 1.5e-3
+    for (k, a), (_, b) in zip(ref.named_parameters(), new.named_parameters()):
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (k, (a - b).abs().max())
+
+    # on the HIP HRNet: parameters re-homed into the flat buffer, training step, eval forward sees the update
+    lrs, alphas, _ = synth.make_batch(9, 2, 4, 16, 4)
+    m = _fresh_model()
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    xs, al = util.dev(lrs), util.dev(alphas)
+    with torch.no_grad():
+        before = m.eval()(xs, al).clone()
+    m.train()
+    for _ in range(3):
+        opt.zero_grad()
+        ((m(xs, al) - 0.1) ** 2).mean().backward()
+        opt.step()
+    with torch.no_grad():
+        after = m.eval()(xs, al)
+    assert float((after - before).abs().max()) > 1e-4
+    assert float(((after - 0.1) ** 2).mean()) < float(((before - 0.1) ** 2).mean())
