@@ -15,6 +15,10 @@
  *   hrn_lanczos_kernel     <-  lanczos.lanczos_kernel(dx, a=3, N=7)   src/lanczos.py:5-43
  *   hrn_*_pack             <-  nn.Module.load_state_dict / .to(device): reference-layout f32 parameters
  *                              (OIHW conv, (Cin,Cout,kH,kW) deconv, (out,in) linear) -> kernel layouts
+ *   hrn_hrnet_forward_train / hrn_hrnet_backward, hrn_shiftnet_forward_train / hrn_shiftnet_backward,
+ *   hrn_lanczos_shift_backward  <-  torch autograd through the three symbols above, src/train.py:172-190
+ *   hrn_adam_step          <-  optimizer.step() of torch.optim.Adam   src/train.py:191, :252
+ *   hrn_get_loss / hrn_shift_cpsnr  <-  get_loss (train.py:66-87) / shift_cPSNR (Evaluator.py:52-73)
  *
  * Conventions
  *   - every pointer is a DEVICE pointer (hipMalloc'ed or a torch CUDA tensor's data_ptr) unless stated;
