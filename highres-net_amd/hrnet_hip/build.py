@@ -70,5 +70,21 @@ def build_library(force=False, verbose=True):
     return LIB
 
 
+IO_SRC = os.path.join(HERE, "csrc_io", "hrnet_io.cpp")
+IO_LIB = os.path.join(HERE, "libhrnet_io.so")
+
+
+def build_io_library(force=False, verbose=True):
+    """Compile the host-side input-pipeline library (g++, zlib, pthreads): libhrnet_io.so."""
+    hdr = os.path.join(HERE, "..", "..", "include", "hrnet_io.h")
+    if force or not os.path.exists(IO_LIB) or os.path.getmtime(IO_LIB) < max(os.path.getmtime(IO_SRC), os.path.getmtime(hdr)):
+        cmd = [os.environ.get("CXX", "g++"), "-O3", "-fPIC", "-shared", "-std=c++17", "-Wall", "-o", IO_LIB, IO_SRC, "-lz", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return IO_LIB
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))
+    print(build_io_library(force="--force" in sys.argv))
