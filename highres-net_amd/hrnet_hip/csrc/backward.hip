@@ -386,11 +386,7 @@ int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int p
                           int M, int H, int W, int cin, int cout, float* dw, void* scratch, int num_cus, hipStream_t s) {
     HRN_CHECK((cin == 64 || cin == 128) && (cout == 64 || cout == 128), -2, "conv_wgrad: unsupported %d -> %d", cin, cout);
     HRN_CHECK(!in_pair || cin == 128, -2, "conv_wgrad: the pair gather has 128 input channels");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HRN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
-        attr_set = true;
-    }
+    { const int rc_lds = hrn_allow_lds((const void*)conv_wgrad_kernel, WG_LDS); if (rc_lds) return rc_lds; }
     static_assert(WG_LDS <= 160 * 1024, "LDS budget");
     const long tiles = (long)((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * M;
     int grid = num_cus;

@@ -318,11 +318,7 @@ int g_num_cus = 0;
 template <int DT, int CIN, int COUT>
 int launch(const ConvParams& p, hipStream_t stream) {
     constexpr int LDS_BYTES = IN_LDS_BYTES + 2 * COUT * W_ROW_PITCH;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HRN_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    { const int rc_lds = hrn_allow_lds((const void*)conv3x3_kernel<DT, CIN, COUT>, LDS_BYTES); if (rc_lds) return rc_lds; }
     if (g_num_cus == 0) {
         int dev = 0, n = 0;
         HRN_HIP(hipGetDevice(&dev));

@@ -303,11 +303,7 @@ int g_r64_cus = 0;
 
 template <bool RES>
 int launch_r64(const ConvParams& p, long grid, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HRN_HIP(hipFuncSetAttribute((const void*)conv3x3_r64_kernel<RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    { const int rc_lds = hrn_allow_lds((const void*)conv3x3_r64_kernel<RES>, LDS_BYTES); if (rc_lds) return rc_lds; }
     hipLaunchKernelGGL(conv3x3_r64_kernel<RES>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
     HRN_LAUNCH_CHECK();
     return 0;

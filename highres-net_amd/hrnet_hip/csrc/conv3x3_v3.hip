@@ -476,11 +476,7 @@ template <int CIN, int COUT, bool OFFLOAD>
 int launch_v3(const ConvParams& p, hipStream_t stream) {
     constexpr int LDS_BYTES = V3Geom<COUT, OFFLOAD>::LDS_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HRN_HIP(hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CIN, COUT, OFFLOAD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    { const int rc_lds = hrn_allow_lds((const void*)conv3x3_v3_kernel<CIN, COUT, OFFLOAD>, LDS_BYTES); if (rc_lds) return rc_lds; }
     if (g_v3_cus == 0) {
         int dev = 0, n = 0;
         HRN_HIP(hipGetDevice(&dev));

@@ -78,3 +78,19 @@ int hrn_profile_get(int idx, char* name, int name_len, long* launches, double* t
     return 0;
 }
 }
+
+// ---- per-device opt-in to more than 64 KB of dynamic LDS for a kernel (hipFuncAttributeMaxDynamicSharedMemorySize is a
+// property of the function ON THE CURRENT DEVICE: a process that switches devices must set it again there)
+#include <set>
+#include <utility>
+int hrn_allow_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    HRN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return 0;
+    HRN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({dev, kernel});
+    return 0;
+}
