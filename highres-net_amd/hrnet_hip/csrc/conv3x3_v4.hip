@@ -183,6 +183,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                     if (c < 3) { issue_in(cur_m, cur_t, c + 1, (c + 1) & 1); issued += n_in; }
                     else if (more_tiles) { issue_in(nxt_m, nxt_t, 0, 0); issued += n_in; }
                 }
+                // ---- residual of the tile (RES): pixel row 0's 8 pieces are fetched before the tile's LAST stage multiplies, pixel
+                // row 1's at the start of the epilogue, so that their HBM latency is covered by MFMA / epilogue work
+                u32x4 rq[2][2][4];                              // [pixel row][cout pair][16-byte piece]
+                auto res_fetch = [&](int pb) __attribute__((always_inline)) {
+                    const int m = (int)cur_m;
+                    const int ty = cur_t / tiles_x;
+                    const int y0 = ty * T4_H, x0 = (cur_t - ty * tiles_x) * T4_W;
+                    const int b = m / p.pair_h, i = m - b * p.pair_h;
+                    const int gy = y0 + 2 * w + pb, gx = x0 + r;
+                    const int gyc = gy < H ? gy : H - 1, gxc = gx < W ? gx : W - 1;
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const unsigned char* view = (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + (pr == 0 ? i : p.pair_last - i)) * hw * 128;
+                        const u32x4* rp = (const u32x4*)(view + (unsigned)((gyc * W + gxc) * 128 + hh * 64));
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rq[pb][pr][g] = rp[g];
+                    }
+                };
+                if (RES && c == 3 && tg == 2) res_fetch(0);
                 // ---- 3 taps x 2 k-steps, fragment reads one step ahead of their MFMAs
                 bf16x8 fa[2][4], fb[2][2];
                 auto load_step = [&](int i, int s_) __attribute__((always_inline)) {
@@ -218,27 +237,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                     if (p.out_h > 0) { const int ob = m / p.out_h, oi = m - ob * p.out_h; oimg = (size_t)ob * p.out_vs + oi; }
                     unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * 256;
                     const int gx = x0 + r;
-                    const unsigned char* rv[2] = {nullptr, nullptr};        // residual: view i (couts 0..63), partner (64..127)
-                    if (RES) {
-                        const int b = m / p.pair_h, i = m - b * p.pair_h;
-                        rv[0] = (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + i) * hw * 128;
-                        rv[1] = (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + (p.pair_last - i)) * hw * 128;
-                    }
+                    if (RES) res_fetch(1);                      // pixel row 1's residual: in flight while row 0 is finished
                     auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
                         constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
                         for (int pb = 0; pb < 2; ++pb) {
                             const int gy = y0 + 2 * w + pb;
                             const bool ok = gy < H && gx < W;
-                            const int gyc = gy < H ? gy : H - 1, gxc = gx < W ? gx : W - 1;
 #pragma unroll
                             for (int pr = 0; pr < 2; ++pr) {            // cout blocks (2pr, 2pr+1) -> channels 64pr + 32hh ..
-                                u32x4 rq[4];
-                                if (RES) {
-                                    const u32x4* rp = (const u32x4*)(rv[pr] + (unsigned)((gyc * W + gxc) * 128 + hh * 64));
-#pragma unroll
-                                    for (int g = 0; g < 4; ++g) rq[g] = rp[g];
-                                }
                                 u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * 256 + pr * 128) + lane_out);
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
@@ -265,8 +272,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                                         }
 #pragma unroll
                                         for (int j = 0; j < 4; ++j) {
-                                            v[2 * j] += __uint_as_float(rq[g][j] << 16);
-                                            v[2 * j + 1] += __uint_as_float(rq[g][j] & 0xffff0000u);
+                                            v[2 * j] += __uint_as_float(rq[pb][pr][g][j] << 16);
+                                            v[2 * j + 1] += __uint_as_float(rq[pb][pr][g][j] & 0xffff0000u);
                                         }
 #pragma unroll
                                         for (int j = 0; j < 4; ++j) u[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
