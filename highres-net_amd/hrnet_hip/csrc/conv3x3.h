@@ -35,8 +35,8 @@ int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream
 // bf16 64 -> 64 with LDS-resident weights (conv3x3_r64.hip); -100 = not applicable, caller picks another kernel.
 int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream);
 
-// bf16 128 -> 128 on 512-pixel tiles with LDS-DMA staging (conv3x3_v4.hip); -100 = not applicable.
-int hrn_launch_conv3x3_v4(const ConvParams& p, hipStream_t stream);
+// bf16 128 -> {128, 64} on 512-pixel tiles with LDS-DMA staging (conv3x3_v4.hip); -100 = not applicable.
+int hrn_launch_conv3x3_v4(int cout, const ConvParams& p, hipStream_t stream);
 
 // Pack OIHW f32 weights [cout][cin][3][3] into the kernel's step-major layout (device to device).
 int hrn_launch_conv_pack(int dt, int cin, int cout, const float* w_oihw, void* packed, hipStream_t stream);

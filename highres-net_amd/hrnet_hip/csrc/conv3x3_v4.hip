@@ -1,20 +1,23 @@
-// conv3x3 128 -> 128, bf16: the fusion residual block's two big layers (HRNet.py:90-95, :123-127) - 47 % of the forward FLOPs.
+// conv3x3 128 -> {128, 64}, bf16: the three layers of a fusion level (HRNet.py:90-97, :123-131) - 61 % of the forward FLOPs.
 //
 // conv3x3_v3 runs these with one MFMA wave per SIMD plus four loader waves that carry every byte HBM/L2 -> VGPR -> LDS;
 // measured there: matrix pipe ~47 % busy, 440 vector-memory instructions and 380 KB of ds_write per 256-pixel tile, the
 // epilogue exposed.  This kernel is built the other way round, after the shape the CDNA4 guide measures fastest for
 // GEMM-like loops (8 waves, two per SIMD, LDS-DMA staging, counted vmcnt, raw barriers):
-//   * 512 output pixels (16 x 32) per tile: the 288 KB of weights stream through LDS once per 512 pixels, not per 256;
-//   * 8 MFMA waves, two per SIMD; wave w owns pixel rows 2w, 2w+1 x all 128 output channels (128 accumulator registers):
-//     6 fragment reads per 8 MFMAs, and each SIMD always has a second wave to issue from while one waits on LDS;
+//   * 512 output pixels (16 x 32) per tile: the weights stream through LDS once per 512 pixels, not per 256;
+//   * 8 MFMA waves, two per SIMD; wave w owns pixel rows 2w, 2w+1 x all COUT output channels (COUT accumulator registers):
+//     COUT = 128: 6 fragment reads per 8 MFMAs, COUT = 64: 4 per 4; each SIMD always has a second wave to issue from while
+//     one waits on LDS;
 //   * all staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no loader waves.  The LDS
 //     images are lane-linear, so the bank swizzle is applied to each lane's SOURCE address and again on the ds_read;
 //   * K is walked as 4 chunks of 32 input channels (64 B per pixel) x 3 tap rows: one stage = 3 taps x 32 channels
-//     = 24 KB of weights (ring of 3) against a double-buffered 18 x 34-pixel halo chunk (39 KB each); 48 MFMAs per wave
-//     and ONE barrier per stage; stage s+2's weights and the next chunk's halo are in flight while stage s multiplies;
+//     (24 KB of weights for COUT = 128, ring of 3) against a double-buffered 18 x 34-pixel halo chunk (39 KB each);
+//     ONE barrier per stage; stage s+2's weights and the next chunk's halo are in flight while stage s multiplies;
 //   * epilogue from the accumulators (bias pre-loaded into them, PReLU, v_permlane32_swap -> 64 contiguous bytes per lane,
-//     residual, one bf16 rounding, 16-byte stores).
-// LDS: 3 x 24,576 (weights) + 2 x 39,936 (halo) + 512 (bias) = 154,112 B.
+//     residual, one bf16 rounding, 16-byte stores); the residual's first half is fetched before the tile's last stage.
+// RESM: 0 no residual | 2 the pair gather z (COUT = 128: t2 = z + PReLU(conv(t1))) | 3 s_i + alpha_partner * f into the
+// view stack (COUT = 64, HRNet.py:123-131).
+// LDS (COUT = 128): 3 x 24,576 (weights) + 2 x 39,936 (halo) + 512 (bias) = 154,112 B.
 // Ordering rules followed (guide, "Pipelining across barriers"): a wave waits for its own DMAs with a counted vmcnt
 // BEFORE the barrier that precedes the stage reading them; a buffer is re-filled only after a barrier that every reader
 // of its previous contents has passed.
@@ -28,10 +31,16 @@ constexpr int HW4 = T4_W + 2;                             // halo width 34
 constexpr int NPIX = (T4_H + 2) * HW4;                    // 612 halo pixels
 constexpr int N_IN_DMA = (NPIX * 64 + 1023) / 1024;       // 39 wave-instructions of 1 KB per halo chunk
 constexpr int IN_BYTES = N_IN_DMA * 1024;                 // 39,936
-constexpr int WST_BYTES = 3 * 128 * 64;                   // 24,576: 3 taps x 128 couts x 32 cin
-constexpr int OFF_IN = 3 * WST_BYTES;
-constexpr int OFF_BIAS = OFF_IN + 2 * IN_BYTES;
-constexpr int LDS_BYTES = OFF_BIAS + 512;
+
+template <int COUT> struct V4Geo {
+    static constexpr int NCB = COUT / 32;                 // 32-channel blocks per wave
+    static constexpr int TAP_BYTES = COUT * 64;           // one tap x 32 cin
+    static constexpr int WST_BYTES = 3 * TAP_BYTES;       // one stage
+    static constexpr int W_PIECES = WST_BYTES / 1024;     // DMA wave-instructions per stage: 24 / 12
+    static constexpr int OFF_IN = 3 * WST_BYTES;
+    static constexpr int OFF_BIAS = OFF_IN + 2 * IN_BYTES;
+    static constexpr int LDS_BYTES = OFF_BIAS + COUT * 4;
+};
 
 __device__ __attribute__((aligned(16))) unsigned hrn_v4_zero16[4];     // source of out-of-image halo pixels
 
@@ -45,10 +54,16 @@ __device__ __forceinline__ float raw_max4(float a, float b) {
     return y;
 }
 __device__ __forceinline__ void wait_vm(int n) {          // counted wait; n is wave-uniform and one of the values below
-    if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    switch (n) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
 }
 __device__ __forceinline__ void lds_done_then_barrier4() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -56,10 +71,14 @@ __device__ __forceinline__ void lds_done_then_barrier4() {
     asm volatile("" ::: "memory");
 }
 
-template <bool RES>
+template <int COUT, int RESM>
 __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) {
+    typedef V4Geo<COUT> GEO;
+    constexpr int NCB = GEO::NCB, NPR = NCB / 2, WST_BYTES = GEO::WST_BYTES, TAP_BYTES = GEO::TAP_BYTES;
+    constexpr int OFF_IN = GEO::OFF_IN, OPIX = COUT * 2;                   // bytes per output pixel
+    constexpr bool RES = RESM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* bias_lds = (float*)(smem + OFF_BIAS);
+    float* bias_lds = (float*)(smem + GEO::OFF_BIAS);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -94,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
 
     // ---- LDS-DMA issue: halo chunk c of tile (m, t) -> input buffer `buf`.  Wave w issues pieces j = w, w+8, ... < 39;
     // piece j, lane i -> LDS bytes j*1024 + i*16 = halo pixel j*16 + (i >> 2), physical 16-B chunk i & 3, which holds
-    // logical chunk (i & 3) ^ ((pixel >> 2) & 3).  Returns the number of DMAs this wave issued.
+    // logical chunk (i & 3) ^ ((pixel >> 2) & 3).
     const int n_in = w < (N_IN_DMA & 7) ? (N_IN_DMA >> 3) + 1 : (N_IN_DMA >> 3);
     auto issue_in = [&](unsigned m, unsigned t, int c, int buf) __attribute__((always_inline)) {
         const int ty = t / tiles_x;
@@ -117,20 +136,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
             }
         }
     };
-    // ---- LDS-DMA issue: weights of stage (chunk c, tap row tg) -> ring slot.  Wave w fetches couts 16w..16w+15 of each of
-    // the three taps (3 DMAs): lane i -> cout 16w + (i >> 2), physical chunk i & 3 = logical (i & 3) ^ ((cout >> 2) & 3).
-    const unsigned w_lane_off = (unsigned)((16 * w + (lane >> 2)) * 128 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    // ---- LDS-DMA issue: weights of stage (chunk c, tap row tg) -> ring slot: W_PIECES pieces of 16 couts x 64 B, piece q =
+    // (tap kx = q / (COUT/16), cout group jj = q % (COUT/16)); wave w issues q = w, w+8, w+16 (< W_PIECES).
+    // lane i -> cout 16jj + (i >> 2), physical chunk i & 3 = logical (i & 3) ^ ((cout >> 2) & 3).
+    constexpr int GPT = COUT / 16;                          // pieces per tap
+    const int n_w = (GEO::W_PIECES - w + 7) / 8;            // 3 (COUT 128) | 2 or 1 (COUT 64)
+    const unsigned w_lane_off = (unsigned)((lane >> 2) * 128 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
     auto issue_w = [&](int c, int tg, int slot_) __attribute__((always_inline)) {
-        const unsigned char* base = (const unsigned char*)p.wpk + (size_t)((c >> 1) * 9 + tg * 3) * 16384 + (c & 1) * 64 + w_lane_off;
+        const unsigned char* base = (const unsigned char*)p.wpk + (size_t)((c >> 1) * 9 + tg * 3) * (COUT * 128) + (c & 1) * 64 + w_lane_off;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) dma16(base + kx * 16384, smem + slot_ * WST_BYTES + kx * 8192 + w * 1024);
+        for (int t = 0; t < 3; ++t) {
+            const int q = w + 8 * t;
+            if (q < GEO::W_PIECES) {
+                const int kx = q / GPT, jj = q - kx * GPT;
+                dma16(base + (size_t)kx * (COUT * 128) + jj * 2048, smem + slot_ * WST_BYTES + kx * TAP_BYTES + jj * 1024);
+            }
+        }
     };
 
     const bool has_slope = p.slope != nullptr;
     const float slope = has_slope ? p.slope[0] : 0.f;
     const bool slope01 = slope >= 0.f && slope <= 1.f;
 
-    // fragment addresses.  Weights: cout row cb*32 + r, k-step ks -> a_off[ks] + cb*2048 + kx*8192 + slot*24576.
+    // fragment addresses.  Weights: cout row cb*32 + r, k-step ks -> a_off[ks] + cb*2048 + kx*TAP_BYTES + slot*WST_BYTES.
     // Input: halo pixel (2w + pb + tg, r + kx) -> b_off[pb + tg][kx] ^ (ks << 5) + buffer base (low bits zero).
     unsigned a_off[2], b_off[4][3];
 #pragma unroll
@@ -142,11 +170,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
             const int pix = (2 * w + row) * HW4 + r + kx;
             b_off[row][kx] = (unsigned)(OFF_IN + pix * 64 + (((hh) ^ ((pix >> 2) & 3)) << 4));
         }
-    const unsigned lane_out = (unsigned)((2 * w * W + r) * 256 + hh * 64);     // byte offset of (row 2w, col r, half hh) in a tile
+    const unsigned lane_out = (unsigned)((2 * w * W + r) * OPIX + hh * 64);    // byte offset of (row 2w, col r, half hh) in a tile
 
-    f32x16 acc[4][2];                                       // [cout block][pixel row]
+    f32x16 acc[NCB][2];                                     // [cout block][pixel row]
 
-    if (tid < 128) bias_lds[tid] = p.bias[tid];
+    if (tid < COUT) bias_lds[tid] = p.bias[tid];
     // prologue: weights of stages 0 and 1, halo chunk 0 of the first tile
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
@@ -161,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
 
         // the accumulators start at the bias (element 4g + j of block cb = channel cb*32 + 8g + 4hh + j)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b = *(const f32x4*)(bias_lds + cb * 32 + 8 * g + 4 * hh);
@@ -178,24 +206,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                     const int tg2 = (tg + 2) % 3, c2 = (c + (tg + 2) / 3) & 3;
                     issue_w(c2, tg2, tg2);
                 }
-                int issued = 3;
+                int issued = n_w;
                 if (tg == 0) {
                     if (c < 3) { issue_in(cur_m, cur_t, c + 1, (c + 1) & 1); issued += n_in; }
                     else if (more_tiles) { issue_in(nxt_m, nxt_t, 0, 0); issued += n_in; }
                 }
-                // ---- residual of the tile (RES): pixel row 0's 8 pieces are fetched before the tile's LAST stage multiplies, pixel
-                // row 1's at the start of the epilogue, so that their HBM latency is covered by MFMA / epilogue work
-                u32x4 rq[2][2][4];                              // [pixel row][cout pair][16-byte piece]
+                // ---- residual of the tile: pixel row 0's pieces are fetched before the tile's LAST stage multiplies, pixel row
+                // 1's at the start of the epilogue, so that their HBM latency is covered by MFMA / epilogue work
+                u32x4 rq[2][NPR][4];                            // [pixel row][cout pair][16-byte piece]
                 auto res_fetch = [&](int pb) __attribute__((always_inline)) {
                     const int m = (int)cur_m;
                     const int ty = cur_t / tiles_x;
                     const int y0 = ty * T4_H, x0 = (cur_t - ty * tiles_x) * T4_W;
-                    const int b = m / p.pair_h, i = m - b * p.pair_h;
                     const int gy = y0 + 2 * w + pb, gx = x0 + r;
                     const int gyc = gy < H ? gy : H - 1, gxc = gx < W ? gx : W - 1;
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const unsigned char* view = (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + (pr == 0 ? i : p.pair_last - i)) * hw * 128;
+                    for (int pr = 0; pr < NPR; ++pr) {
+                        const unsigned char* view;
+                        if (RESM == 2) {                        // z: channels 0..63 = view i, 64..127 = its partner
+                            const int b = m / p.pair_h, i = m - b * p.pair_h;
+                            view = (const unsigned char*)p.stack + ((size_t)b * p.pair_vs + (pr == 0 ? i : p.pair_last - i)) * hw * 128;
+                        } else {                                // s_i of the view stack (the slot the output replaces)
+                            const int b = m / p.out_h, i = m - b * p.out_h;
+                            view = (const unsigned char*)p.res + ((size_t)b * p.res_vs + i) * hw * 128;
+                        }
                         const u32x4* rp = (const u32x4*)(view + (unsigned)((gyc * W + gxc) * 128 + hh * 64));
 #pragma unroll
                         for (int g = 0; g < 4; ++g) rq[pb][pr][g] = rp[g];
@@ -203,12 +237,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                 };
                 if (RES && c == 3 && tg == 2) res_fetch(0);
                 // ---- 3 taps x 2 k-steps, fragment reads one step ahead of their MFMAs
-                bf16x8 fa[2][4], fb[2][2];
+                bf16x8 fa[2][NCB], fb[2][2];
                 auto load_step = [&](int i, int s_) __attribute__((always_inline)) {
                     const int kx = i >> 1, ks = i & 1;
-                    const unsigned char* wb = smem + tg * WST_BYTES + kx * 8192 + a_off[ks];
+                    const unsigned char* wb = smem + tg * WST_BYTES + kx * TAP_BYTES + a_off[ks];
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) fa[s_][cb] = *(const bf16x8*)(wb + cb * 2048);
+                    for (int cb = 0; cb < NCB; ++cb) fa[s_][cb] = *(const bf16x8*)(wb + cb * 2048);
 #pragma unroll
                     for (int pb = 0; pb < 2; ++pb)
                         fb[s_][pb] = *(const bf16x8*)(smem + ((b_off[pb + tg][kx] + inbase) ^ (unsigned)(ks << 5)));
@@ -219,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                     if (i + 1 < 6) load_step(i + 1, (i + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
+                    for (int cb = 0; cb < NCB; ++cb) {
                         acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][cb], fb[i & 1][0], acc[cb][0], 0, 0, 0);
                         acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][cb], fb[i & 1][1], acc[cb][1], 0, 0, 0);
                     }
@@ -234,8 +268,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                     const int ty = cur_t / tiles_x;
                     const int y0 = ty * T4_H, x0 = (cur_t - ty * tiles_x) * T4_W;
                     size_t oimg = (size_t)m;
-                    if (p.out_h > 0) { const int ob = m / p.out_h, oi = m - ob * p.out_h; oimg = (size_t)ob * p.out_vs + oi; }
-                    unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * 256;
+                    float res_alpha = 1.f;
+                    if (p.out_h > 0) {
+                        const int ob = m / p.out_h, oi = m - ob * p.out_h;
+                        oimg = (size_t)ob * p.out_vs + oi;
+                        if (RESM == 3 && p.alphas) res_alpha = p.alphas[(size_t)ob * p.alpha_vs + (p.pair_last - oi)];
+                    }
+                    unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * OPIX;
                     const int gx = x0 + r;
                     if (RES) res_fetch(1);                      // pixel row 1's residual: in flight while row 0 is finished
                     auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
@@ -245,8 +284,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                             const int gy = y0 + 2 * w + pb;
                             const bool ok = gy < H && gx < W;
 #pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {            // cout blocks (2pr, 2pr+1) -> channels 64pr + 32hh ..
-                                u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * 256 + pr * 128) + lane_out);
+                            for (int pr = 0; pr < NPR; ++pr) {          // cout blocks (2pr, 2pr+1) -> channels 64pr + 32hh ..
+                                u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * OPIX + pr * 128) + lane_out);
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
                                     float xa[4], xb[4];
@@ -272,8 +311,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                                         }
 #pragma unroll
                                         for (int j = 0; j < 4; ++j) {
-                                            v[2 * j] += __uint_as_float(rq[pb][pr][g][j] << 16);
-                                            v[2 * j + 1] += __uint_as_float(rq[pb][pr][g][j] & 0xffff0000u);
+                                            const float r0 = __uint_as_float(rq[pb][pr][g][j] << 16), r1 = __uint_as_float(rq[pb][pr][g][j] & 0xffff0000u);
+                                            if (RESM == 3) { v[2 * j] = r0 + res_alpha * v[2 * j]; v[2 * j + 1] = r1 + res_alpha * v[2 * j + 1]; }
+                                            else { v[2 * j] += r0; v[2 * j + 1] += r1; }
                                         }
 #pragma unroll
                                         for (int j = 0; j < 4; ++j) u[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
@@ -301,21 +341,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
 
 int g_v4_cus = 0;
 
-template <bool RES>
+template <int COUT, int RESM>
 int launch_v4(const ConvParams& p, long grid, hipStream_t stream) {
-    { const int rc_lds = hrn_allow_lds((const void*)conv3x3_v4_kernel<RES>, LDS_BYTES); if (rc_lds) return rc_lds; }
-    hipLaunchKernelGGL(conv3x3_v4_kernel<RES>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
+    typedef V4Geo<COUT> GEO;
+    static_assert(GEO::LDS_BYTES <= 160 * 1024, "LDS budget");
+    { const int rc_lds = hrn_allow_lds((const void*)conv3x3_v4_kernel<COUT, RESM>, GEO::LDS_BYTES); if (rc_lds) return rc_lds; }
+    hipLaunchKernelGGL((conv3x3_v4_kernel<COUT, RESM>), dim3((unsigned)grid), dim3(512), GEO::LDS_BYTES, stream, p);
     HRN_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-// bf16 128 -> 128, residual none or the pair gather (res_mode 2).  Returns -100 when not applicable.
-int hrn_launch_conv3x3_v4(const ConvParams& p, hipStream_t stream) {
-    if (p.scale || p.relu || (p.res_mode != 0 && p.res_mode != 2)) return -100;
+// bf16, 128 input channels.  COUT = 128: residual none or the pair gather (res_mode 2); COUT = 64: none or the alpha residual into
+// the view stack (res_mode 3).  Returns -100 when not applicable.
+int hrn_launch_conv3x3_v4(int cout, const ConvParams& p, hipStream_t stream) {
+    if (p.scale || p.relu) return -100;
+    if (cout == 128 && p.res_mode != 0 && p.res_mode != 2) return -100;
+    if (cout == 64 && ((p.res_mode != 0 && p.res_mode != 3) || p.in_pair)) return -100;
+    if (cout != 64 && cout != 128) return -100;
     if ((p.in_pair || p.res_mode == 2) && p.pair_h <= 0) return -100;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    if (p.res_mode == 3 && (p.out_h <= 0 || !p.res)) return -100;
     if (g_v4_cus == 0) {
         int dev = 0, n = 0;
         HRN_HIP(hipGetDevice(&dev));
@@ -330,7 +376,9 @@ int hrn_launch_conv3x3_v4(const ConvParams& p, hipStream_t stream) {
     if (total < grid) grid = total;
     if (grid >= 8) grid &= ~7L;
     const double px = (double)p.M * p.H * p.W;
-    HrnProfScope prof(p.res_mode ? "conv3x3_bf16_128x128+res" : "conv3x3_bf16_128x128", 2.0 * 128 * 128 * 9 * px,
-                      px * 2 * (128 + 128 + (p.res_mode ? 128 : 0)), stream);
-    return p.res_mode ? launch_v4<true>(p, grid, stream) : launch_v4<false>(p, grid, stream);
+    const char* fam = cout == 128 ? (p.res_mode ? "conv3x3_bf16_128x128+res" : "conv3x3_bf16_128x128")
+                                  : (p.res_mode ? "conv3x3_bf16_128x64+res" : "conv3x3_bf16_128x64");
+    HrnProfScope prof(fam, 2.0 * 128 * cout * 9 * px, px * 2 * (128 + cout + (p.res_mode ? cout : 0)), stream);
+    if (cout == 128) return p.res_mode ? launch_v4<128, 2>(p, grid, stream) : launch_v4<128, 0>(p, grid, stream);
+    return p.res_mode ? launch_v4<64, 3>(p, grid, stream) : launch_v4<64, 0>(p, grid, stream);
 }
