@@ -514,6 +514,13 @@ int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t st
         if (r64) { const int rc = hrn_launch_conv3x3_r64(p, stream); if (rc != -100) return rc; }
         return offload ? launch_v3<64, 64, true>(p, stream) : launch_v3<64, 64, false>(p, stream);
     }
+    if (cin == 128 && cout == 128) {
+        // the same structure on v_mfma_f32_16x16x32_bf16 (conv3x3_v5.hip).  HRN_CONV_V5 = 0: off, 1 (default): layers without a
+        // residual, 2: with the pair-gather residual too (ties v4 there)
+        static int v5 = -1;
+        if (v5 < 0) { const char* e = getenv("HRN_CONV_V5"); v5 = e ? atoi(e) : 1; }
+        if (v5 >= (p.res_mode ? 2 : 1)) { const int rc = hrn_launch_conv3x3_v5(p, stream); if (rc != -100) return rc; }
+    }
     if (cin == 128) {
         // 512-pixel-tile, 8-MFMA-wave, LDS-DMA kernel (conv3x3_v4.hip) for the fusion level's three layers;
         // HRN_CONV_V4 = 0: off, 1 (default): 128 -> 128 only, 2: 128 -> 64 as well.  For 128 -> 64 the two kernels measure the
