@@ -255,3 +255,31 @@ def test_bf16_kernels_on_awkward_sizes_vs_fp32_path(S, V):
         again = util.hip_hrnet("bf16")(x, a).cpu().numpy()
     assert np.isfinite(got).all() and np.array_equal(got, again)
     assert util.rel_err(got, ref) <= 4e-2 and util.psnr_db(got, ref) >= 42.0
+
+
+def test_forward_is_graph_capturable():
+    """The C ABI promises that calls only enqueue work (no allocation, no synchronisation, no host read-back; include/hrnet_hip.h):
+    capture HRNet.forward (bf16, all conv kernels incl. the LDS-DMA ones) into a HIP graph and replay it on new inputs."""
+    lrs, alphas = synth.fast_batch(61, 2, 6, 64)
+    lrs2, _ = synth.fast_batch(62, 2, 6, 64)
+    m = util.hip_hrnet("bf16")
+    x, a = util.dev(lrs).clone(), util.dev(alphas)
+    with torch.no_grad():
+        eager1 = m(x, a).clone()                              # warm-up: packs parameters, sizes the workspace, sets LDS limits
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x, a)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            out = m(x, a)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager1)
+        x.copy_(util.dev(lrs2))                               # new data in the captured input buffer
+        g.replay()
+        torch.cuda.synchronize()
+        replayed = out.clone()
+        eager2 = m(x, a)
+    assert torch.equal(replayed, eager2) and not torch.equal(eager1, eager2)
