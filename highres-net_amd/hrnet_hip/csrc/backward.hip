@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    for (long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    // The next tile's x halo (340 px x 16 float4) and g tile (256 px x 16 float4) travel HBM -> registers while the current tile
+    // is multiplied (one wave per SIMD: 512 registers, 144 of them accumulators), and registers -> LDS between two barriers.
+    constexpr int NXR = (WG_HH * WG_HW * 16 + 255) / 256, NGR = WG_TH * WG_TW * 16 / 256;      // 22, 16 float4 per thread
+    f32x4 xreg[NXR], greg[NGR];
+    auto issue = [&](long tl) __attribute__((always_inline)) {
         const int m = (int)(tl / tiles);
         const int t = (int)(tl - (long)m * tiles);
         const int ty = t / tiles_x, y0 = ty * WG_TH, x0 = (t - ty * tiles_x) * WG_TW;
@@ -160,41 +164,69 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
             xpitch = p.cin;
         }
         const float* gb = p.g + (size_t)m * hw * p.cout + p.co_chunk * 64;
-        __syncthreads();                                        // previous tile's MFMA reads are done
-        // x halo tile: 340 px x 16 float4
-        for (int q = tid; q < WG_HH * WG_HW * 16; q += 256) {
+#pragma unroll
+        for (int it = 0; it < NXR; ++it) {
+            const int q = tid + it * 256;
             const int pix = q >> 4, part = q & 15;
             const int py = pix / WG_HW, px = pix - py * WG_HW;
             const int gy = y0 + py - 1, gx = x0 + px - 1;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *(const f32x4*)(xb + ((size_t)gy * W + gx) * xpitch + part * 4);
-            *(f32x4*)(xs + pix * WG_XP + part * 4) = v;
+            if (q < WG_HH * WG_HW * 16 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v = *(const f32x4*)(xb + ((size_t)gy * W + gx) * xpitch + part * 4);
+            xreg[it] = v;
         }
-        // g tile: 256 px x 16 float4 (zero outside the image: those pixels contribute nothing)
-        for (int q = tid; q < WG_TH * WG_TW * 16; q += 256) {
+#pragma unroll
+        for (int it = 0; it < NGR; ++it) {                      // zero outside the image: those pixels contribute nothing
+            const int q = tid + it * 256;
             const int pix = q >> 4, part = q & 15;
             const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gy < H && gx < W) v = *(const f32x4*)(gb + ((size_t)gy * W + gx) * p.cout + part * 4);
-            *(f32x4*)(gs + pix * WG_GP + part * 4) = v;
+            greg[it] = v;
+        }
+    };
+    if ((long)blockIdx.x < total) issue(blockIdx.x);
+    for (long tl = blockIdx.x; tl < total; tl += gridDim.x) {
+        __syncthreads();                                        // previous tile's MFMA reads are done
+#pragma unroll
+        for (int it = 0; it < NXR; ++it) {
+            const int q = tid + it * 256;
+            if (q < WG_HH * WG_HW * 16) *(f32x4*)(xs + (q >> 4) * WG_XP + (q & 15) * 4) = xreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NGR; ++it) {
+            const int q = tid + it * 256;
+            *(f32x4*)(gs + (q >> 4) * WG_GP + (q & 15) * 4) = greg[it];
         }
         __syncthreads();
+        if (tl + gridDim.x < total) issue(tl + gridDim.x);      // in flight during this tile's MFMAs
         // 128 k-steps of two pixels: A[co = r][k = hh] = g[pixel 2s + hh][cb*32 + r], B[k = hh][ci = r] = x[pixel + tap][ib*32 + r]
         const float* ga = gs + hh * WG_GP + cb * 32 + r;
         const float* xa = xs + hh * WG_XP + ib * 32 + r;
-#pragma unroll 2
-        for (int s = 0; s < 128; ++s) {
+        // operands of k-step s+1 are read while the nine MFMAs of k-step s run (the compiler otherwise waits for each
+        // k-step's ten ds_reads right in front of its MFMAs); sched_barrier pins the order
+        float a_cur, b_cur[9], a_nxt = 0.f, b_nxt[9];
+        auto fetch = [&](int s, float& a, float (&b)[9]) __attribute__((always_inline)) {
             const int pp = 2 * s;                               // even pixel of the pair; both pixels share the tile row
             const int row = pp >> 5, col = pp & 31;
-            const float a = ga[pp * WG_GP];
+            a = ga[pp * WG_GP];
             const float* xr = xa + (row * WG_HW + col) * WG_XP;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float b = xr[(ky * WG_HW + kx) * WG_XP];
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * 3 + kx], 0, 0, 0);
-                }
+                for (int kx = 0; kx < 3; ++kx) b[ky * 3 + kx] = xr[(ky * WG_HW + kx) * WG_XP];
+        };
+        fetch(0, a_cur, b_cur);
+#pragma unroll 2
+        for (int s = 0; s < 128; ++s) {
+            if (s + 1 < 128) fetch(s + 1, a_nxt, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
         }
     }
     // partial[blk][tap][co 64][ci 64]; accumulator element (g4, j) of lane (r = ci column, hh) is row co = 8*g4 + 4*hh + j
