@@ -66,19 +66,34 @@ __global__ __launch_bounds__(256) void scalar_finish_kernel(const double* __rest
 // ------------------------------------------------------------------------------------------------ column sums (bias grads)
 template <int C>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, size_t rows, double* __restrict__ partial) {
-    // thread -> channel c = tid % C, row phase tid / C; rows strided by gridDim * (256 / C)
-    constexpr int RP = 256 / C;
-    const int c = threadIdx.x % C, rp = threadIdx.x / C;
-    double acc = 0.0;
-    for (size_t r = (size_t)blockIdx.x * RP + rp; r < rows; r += (size_t)gridDim.x * RP) acc += (double)g[r * C + c];
-    __shared__ double red[256];
-    red[threadIdx.x] = acc;
+    // thread -> 4 channels c4*4.., row phase tid / (C/4); 16-byte loads, four rows in flight per thread; fixed order
+    constexpr int C4 = C / 4, RP = 256 / C4;
+    const int c4 = threadIdx.x % C4, rp = threadIdx.x / C4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const size_t stride = (size_t)gridDim.x * RP;
+    size_t r = (size_t)blockIdx.x * RP + rp;
+    for (; r + 3 * stride < rows; r += 4 * stride) {
+        const f32x4 v0 = *(const f32x4*)(g + r * C + c4 * 4), v1 = *(const f32x4*)(g + (r + stride) * C + c4 * 4);
+        const f32x4 v2 = *(const f32x4*)(g + (r + 2 * stride) * C + c4 * 4), v3 = *(const f32x4*)(g + (r + 3 * stride) * C + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += ((double)v0[j] + (double)v1[j]) + ((double)v2[j] + (double)v3[j]);
+    }
+    for (; r < rows; r += stride) {
+        const f32x4 v = *(const f32x4*)(g + r * C + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += (double)v[j];
+    }
+    __shared__ double red[4][256];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[j][threadIdx.x] = acc[j];
     __syncthreads();
     if (rp == 0) {
-        double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < RP; ++k) s += red[k * C + c];
-        partial[(size_t)blockIdx.x * C + c] = s;
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < RP; ++k) s += red[j][k * C4 + c4];
+            partial[(size_t)blockIdx.x * C + c4 * 4 + j] = s;
+        }
     }
 }
 // out[c] += sum over blocks of partial[b][c]: one block per 32 channels, 8 block-phases per channel, fixed order
