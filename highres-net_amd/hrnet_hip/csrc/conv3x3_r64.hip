@@ -124,15 +124,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
     // fragment addresses.  Weights: row r of cout block cb, k-step ks -> a_off[ks] + cb*4096 + tap*8192.
     // Input: halo pixel (2*tw + pb + ky, r + kx), k-step ks -> b_off[pb + ky][kx] ^ (ks << 5)   (12 registers, not 72;
     // the buffer base has zero low bits, so it is folded in before the xor)
-    unsigned a_off[4], b_off[4][3];
+    // All of them are absolute LDS byte addresses (the fragment reads are hand-written ds_read_b128, see multiply()); the
+    // 16-bit instruction offset reaches taps 0-3 from a_off and taps 4-8 from a_off_hi.
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned a_off[4], a_off_hi[4], b_off[4][3];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) a_off[ks] = r * 128 + (((ks * 2 + hh) ^ ((r >> 1) & 7)) << 4);
+    for (int ks = 0; ks < 4; ++ks) {
+        a_off[ks] = lds0 + r * 128 + (((ks * 2 + hh) ^ ((r >> 1) & 7)) << 4);
+        a_off_hi[ks] = a_off[ks] + 4 * 8192;
+    }
 #pragma unroll
     for (int row = 0; row < 4; ++row)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int pix = (2 * tw + row) * HALO_W + r + kx;
-            b_off[row][kx] = (unsigned)(W_BYTES + team * IN_BYTES) + (((unsigned)pix << 7) | ((unsigned)(((pix >> 1) & 7) ^ hh) << 4));
+            b_off[row][kx] = lds0 + (unsigned)(W_BYTES + team * IN_BYTES) + (((unsigned)pix << 7) | ((unsigned)(((pix >> 1) & 7) ^ hh) << 4));
         }
 
     const unsigned lane_off = (unsigned)((2 * tw * W + r) * 128 + hh * 64);
@@ -149,32 +155,66 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[cb][0][4 * g + j] = b[j]; acc[cb][1][4 * g + j] = b[j]; }
             }
-        constexpr int NK = 36, DEPTH = 2;
-        bf16x8 fa[DEPTH + 1][2], fb[DEPTH + 1][2];
-        auto load_k = [&](int i, int s_) __attribute__((always_inline)) {
-            const int tap = i >> 2, ks = i & 3;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const unsigned char* wb = w_lds + tap * 8192 + a_off[ks];
-            fa[s_][0] = *(const bf16x8*)(wb);
-            fa[s_][1] = *(const bf16x8*)(wb + 4096);
-            unsigned kbits = 0;
-            if (ks) asm volatile("s_mov_b32 %0, %1" : "=s"(kbits) : "n"(ks << 5));     // opaque: keeps the compiler from
-#pragma unroll                                                                          // materialising all 72 addresses
-            for (int pb = 0; pb < 2; ++pb) fb[s_][pb] = *(const bf16x8*)(smem + (b_off[pb + ky][kx] ^ kbits));
+        // Hand-issued fragment stream.  In a kernel that also issues LDS-DMA hipcc does not count LDS waits: it answers
+        // every fragment use with s_waitcnt lgkmcnt(0), which waits for the reads issued a moment ago as well and exposed
+        // the whole LDS latency every third k-step (in-kernel stamps: 6,800 cycles per tile for 4,608 cycles of MFMA).  So
+        // the ds_read_b128 are inline asm - invisible to the compiler's wait insertion - and are waited for with counted
+        // lgkmcnt here; and they are spread one per MFMA gap instead of four in a burst in front of the four MFMAs (all
+        // four waves of the team burst together, and an MFMA cannot issue before the reads in front of it have).
+        //   gap 0: A0(i+2)   gap 1: A1(i+2)   gap 2: B0(i+2)   gap 3: B1(i+2)     [A = weights, B = pixels, two steps ahead]
+        // MFMA order (cout block, pixel row) = (0,0) (0,1) (1,0) (1,1).  LDS reads return in order, so before (0,0) of step
+        // i the reads A0(i), A1(i), B0(i) are back once at most the five younger ones - B1(i) and the four of step i+1 -
+        // are outstanding: lgkmcnt(5); before (0,1), B1(i): the four of step i+1 and A0(i+2): lgkmcnt(5) again.  The last
+        // two steps issue nothing and count down.  The asm statements are volatile: they keep their order, and each wait
+        // names the fragments it guards as in/out operands, so no MFMA can move in front of its wait.  The reads of one
+        // gap may be scheduled in front of that gap's MFMA but never across the sched_barrier to another gap's wait.
+        constexpr int NK = 36;
+        bf16x8 fa[3][2], fb[3][2];
+        auto rd = [&](bf16x8& dst, unsigned addr, int imm) __attribute__((always_inline)) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
         };
+        auto load_part = [&](int i, int part) __attribute__((always_inline)) {
+            const int s_ = i % 3, tap = i >> 2, ks = i & 3;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            if (part < 2) {
+                rd(fa[s_][part], tap < 4 ? a_off[ks] : a_off_hi[ks], (tap < 4 ? tap : tap - 4) * 8192 + part * 4096);
+            } else {
+                unsigned kbits = 0;
+                if (ks) asm volatile("s_mov_b32 %0, %1" : "=s"(kbits) : "n"(ks << 5));     // opaque: keeps the compiler from
+                rd(fb[s_][part - 2], b_off[part - 2 + ky][kx] ^ kbits, 0);                  // materialising all 72 addresses
+            }
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // nothing of the compiler's own left in the LGKM queue
+        __builtin_amdgcn_s_setprio(3);                              // the matrix-pipe stream wins issue ties against the OFF team
 #pragma unroll
-        for (int i = 0; i < DEPTH; ++i) load_k(i, i);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int part = 0; part < 4; ++part) load_part(i, part);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-            if (i + DEPTH < NK) load_k(i + DEPTH, (i + DEPTH) % (DEPTH + 1));
+            const int s_ = i % 3;
+            const bool more = i + 2 < NK;
+            if (i < NK - 1) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[s_][0]), "+v"(fb[s_][0]));
+            else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[s_][0]), "+v"(fb[s_][0]));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][0], fb[s_][0], acc[0][0], 0, 0, 0);
+            if (more) load_part(i + 2, 0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % (DEPTH + 1)][cb], fb[i % (DEPTH + 1)][0], acc[cb][0], 0, 0, 0);
-                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % (DEPTH + 1)][cb], fb[i % (DEPTH + 1)][1], acc[cb][1], 0, 0, 0);
-            }
+            if (more) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fb[s_][1]));
+            else if (i == NK - 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fb[s_][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[s_][1]));
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][0], fb[s_][1], acc[0][1], 0, 0, 0);
+            if (more) load_part(i + 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(fa[s_][1]));                     // A1(i) is older than B0(i): already back
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][1], fb[s_][0], acc[1][0], 0, 0, 0);
+            if (more) load_part(i + 2, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][1], fb[s_][1], acc[1][1], 0, 0, 0);
+            if (more) load_part(i + 2, 3);
             __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- residual of the tile at the cursor: the 64 bytes this lane will own after the swap (channels 32*hh .. 32*hh+31
