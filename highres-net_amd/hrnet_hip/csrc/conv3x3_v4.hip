@@ -160,15 +160,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
 
     // fragment addresses.  Weights: cout row cb*32 + r, k-step ks -> a_off[ks] + cb*2048 + kx*TAP_BYTES + slot*WST_BYTES.
     // Input: halo pixel (2w + pb + tg, r + kx) -> b_off[pb + tg][kx] ^ (ks << 5) + buffer base (low bits zero).
-    unsigned a_off[2], b_off[4][3];
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned a_off[2], a_off_hi[2], b_off[4][3];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a_off[ks] = (unsigned)(r * 64 + (((ks * 2 + hh) ^ ((r >> 2) & 3)) << 4));
+    for (int ks = 0; ks < 2; ++ks) { a_off[ks] = lds0 + (unsigned)(r * 64 + (((ks * 2 + hh) ^ ((r >> 2) & 3)) << 4)); a_off_hi[ks] = a_off[ks] + 32768; }
 #pragma unroll
     for (int row = 0; row < 4; ++row)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int pix = (2 * w + row) * HW4 + r + kx;
-            b_off[row][kx] = (unsigned)(OFF_IN + pix * 64 + (((hh) ^ ((pix >> 2) & 3)) << 4));
+            b_off[row][kx] = lds0 + (unsigned)(OFF_IN + pix * 64 + (((hh) ^ ((pix >> 2) & 3)) << 4));
         }
     const unsigned lane_out = (unsigned)((2 * w * W + r) * OPIX + hh * 64);    // byte offset of (row 2w, col r, half hh) in a tile
 
@@ -199,18 +200,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
 
         for (int c = 0; c < 4; ++c) {
             const unsigned inbase = (unsigned)((c & 1) * IN_BYTES);
-#pragma unroll
-            for (int tg = 0; tg < 3; ++tg) {
-                // ---- in flight during this stage: weights of stage s+2 (ring slot (tg+2)%3), and at tg == 0 the next halo chunk
-                {
+            auto stage = [&](auto tg_c) __attribute__((always_inline)) {
+                constexpr int tg = decltype(tg_c)::value;
+                // ---- in flight during this stage: weights of stage s+2 (ring slot (tg+2)%3), and at tg == 0 the next halo chunk.
+                // The two waves of a SIMD (w, w+4) take the matrix pipe one after the other, so waves 4-7 issue their DMAs
+                // before their MFMAs (while waves 0-3 multiply) and waves 0-3 after theirs (while waves 4-7 multiply).
+                int issued = n_w;
+                if (tg == 0 && (c < 3 || more_tiles)) issued += n_in;
+                auto stage_issue = [&]() __attribute__((always_inline)) {
                     const int tg2 = (tg + 2) % 3, c2 = (c + (tg + 2) / 3) & 3;
                     issue_w(c2, tg2, tg2);
-                }
-                int issued = n_w;
-                if (tg == 0) {
-                    if (c < 3) { issue_in(cur_m, cur_t, c + 1, (c + 1) & 1); issued += n_in; }
-                    else if (more_tiles) { issue_in(nxt_m, nxt_t, 0, 0); issued += n_in; }
-                }
+                    if (tg == 0) {
+                        if (c < 3) issue_in(cur_m, cur_t, c + 1, (c + 1) & 1);
+                        else if (more_tiles) issue_in(nxt_m, nxt_t, 0, 0);
+                    }
+                };
+                if (w >= 4) stage_issue();
                 // ---- residual of the tile: pixel row 0's pieces are fetched before the tile's LAST stage multiplies, pixel row
                 // 1's at the start of the epilogue, so that their HBM latency is covered by MFMA / epilogue work
                 u32x4 rq[2][NPR][4];                            // [pixel row][cout pair][16-byte piece]
@@ -237,28 +242,49 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                 };
                 if (RES && c == 3 && tg == 2) res_fetch(0);
                 // ---- 3 taps x 2 k-steps, fragment reads one step ahead of their MFMAs
+                // Hand-issued fragment reads (see conv3x3_r64.hip: with LDS-DMA in the kernel hipcc answers every fragment use
+                // with lgkmcnt(0)).  Reads of step i+1 go one per MFMA gap of step i, in the order A[0..NCB-1], B0, B1; the
+                // MFMAs run (cb, pb) = (0,0) (0,1) (1,0) ...  LDS reads return in order: before (0,0) of step i, A[*](i) and
+                // B0(i) are back once at most B1(i) is outstanding: lgkmcnt(1); before (0,1), B1(i): only A0(i+1), issued in
+                // gap 0, is younger: lgkmcnt(1) (0 in the last step, which issues nothing).
                 bf16x8 fa[2][NCB], fb[2][2];
-                auto load_step = [&](int i, int s_) __attribute__((always_inline)) {
-                    const int kx = i >> 1, ks = i & 1;
-                    const unsigned char* wb = smem + tg * WST_BYTES + kx * TAP_BYTES + a_off[ks];
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) fa[s_][cb] = *(const bf16x8*)(wb + cb * 2048);
-#pragma unroll
-                    for (int pb = 0; pb < 2; ++pb)
-                        fb[s_][pb] = *(const bf16x8*)(smem + ((b_off[pb + tg][kx] + inbase) ^ (unsigned)(ks << 5)));
+                auto rd = [&](bf16x8& dst, unsigned addr, int imm) __attribute__((always_inline)) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
                 };
-                load_step(0, 0);
+                auto load_part = [&](int i, int part) __attribute__((always_inline)) {
+                    const int s_ = i & 1, kx = i >> 1, ks = i & 1;
+                    if (part < NCB) {
+                        const int off = tg * WST_BYTES + kx * TAP_BYTES + part * 2048;
+                        rd(fa[s_][part], off < 32768 ? a_off[ks] : a_off_hi[ks], off < 32768 ? off : off - 32768);
+                    } else {
+                        unsigned kbits = 0;
+                        if (ks) asm volatile("s_mov_b32 %0, 32" : "=s"(kbits));
+                        rd(fb[s_][part - NCB], (b_off[part - NCB + tg][kx] + inbase) ^ kbits, 0);
+                    }
+                };
+#pragma unroll
+                for (int part = 0; part < NCB + 2; ++part) load_part(0, part);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    if (i + 1 < 6) load_step(i + 1, (i + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    const int s_ = i & 1;
+                    const bool more = i + 1 < 6;
 #pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) {
-                        acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][cb], fb[i & 1][0], acc[cb][0], 0, 0, 0);
-                        acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][cb], fb[i & 1][1], acc[cb][1], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb) {
+                            const int g = cb * 2 + pb;              // MFMA gap index
+                            if (g == 0) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[s_][0]), "+v"(fb[s_][0]));
+                            else if (g == 1) {
+                                if (more) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fb[s_][1]));
+                                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[s_][1]));
+                            } else if (pb == 0) asm volatile("" : "+v"(fa[s_][cb]));
+                            acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][cb], fb[s_][pb], acc[cb][pb], 0, 0, 0);
+                            if (more && g < NCB + 2) load_part(i + 1, g);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                 }
+                if (w < 4) stage_issue();
                 // everything issued before this stage has landed once only this stage's DMAs are outstanding:
                 // stage s+1's weights (issued in stage s-1) and any halo chunk issued then
                 wait_vm(issued);
@@ -332,7 +358,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                     else epilogue(std::integral_constant<int, 2>{});
                 }
                 lds_done_then_barrier4();
-            }
+            };
+            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 2>{});
         }
         cur_m = nxt_m; cur_t = nxt_t;
     }

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
 
     // A fragment of cout block cb (16 rows): a_off + cb*1024 + kx*TAP + slot*WST.  B fragment of pixel block pxb = (row pxb >> 1,
     // column half pxb & 1): halo pixel pixb[pxb] + tg*34 + kx, computed per use (one add + swizzle).
-    const unsigned a_off = (unsigned)(c15 * 64 + ((q ^ swz5(c15)) << 4));
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned a_off = lds0 + (unsigned)(c15 * 64 + ((q ^ swz5(c15)) << 4)), a_off_hi = a_off + 32768;
     int pixb[4];
 #pragma unroll
     for (int pxb = 0; pxb < 4; ++pxb) pixb[pxb] = (2 * w + (pxb >> 1)) * HW5 + 16 * (pxb & 1) + c15;
@@ -155,17 +156,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
         }
         for (int c = 0; c < 4; ++c) {
             const unsigned inbase = (unsigned)(OFF_IN5 + (c & 1) * IN_BYTES5);
-#pragma unroll
-            for (int tg = 0; tg < 3; ++tg) {
-                {
+            auto stage = [&](auto tg_c) __attribute__((always_inline)) {
+                constexpr int tg = decltype(tg_c)::value;
+                // DMAs in flight during this stage: weights of stage s+2, at tg == 0 the next halo chunk.  The two waves of a SIMD
+                // (w, w+4) take the matrix pipe one after the other: waves 4-7 issue before their MFMAs, waves 0-3 after theirs.
+                int issued = 3;
+                if (tg == 0 && (c < 3 || more_tiles)) issued += n_in;
+                auto stage_issue = [&]() __attribute__((always_inline)) {
                     const int tg2 = (tg + 2) % 3, c2 = (c + (tg + 2) / 3) & 3;
                     issue_w(c2, tg2, tg2);
-                }
-                int issued = 3;
-                if (tg == 0) {
-                    if (c < 3) { issue_in(cur_m, cur_t, c + 1, (c + 1) & 1); issued += n_in; }
-                    else if (more_tiles) { issue_in(nxt_m, nxt_t, 0, 0); issued += n_in; }
-                }
+                    if (tg == 0) {
+                        if (c < 3) issue_in(cur_m, cur_t, c + 1, (c + 1) & 1);
+                        else if (more_tiles) issue_in(nxt_m, nxt_t, 0, 0);
+                    }
+                };
+                if (w >= 4) stage_issue();
                 // residual pieces: [pixel block][cout pair n]: 16 bytes each
                 u32x4 rq[4][4];
                 auto res_fetch = [&](int prow) __attribute__((always_inline)) {
@@ -185,40 +190,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
                         }
                     }
                 };
-                // ---- 3 taps x 2 cout halves; B fragments once per tap, A fragments per step, one step ahead
+                // ---- 12 steps = 3 taps x 4 cout quarters, 8 MFMAs each ((k, pxb): cout block 2qt+k x pixel block pxb).
+                // Hand-issued fragment reads with counted waits (see conv3x3_r64.hip for why).  Program order of the reads:
+                // prologue B0..B3(tap 0), A0(0), A1(0); step i: A0(i+1) after MFMA 0, A1(i+1) after MFMA 1, and in the second
+                // step of a tap the next tap's B0..B3 after MFMAs 2..5.  LDS reads return in order; A0(i) is younger than every
+                // B of its tap, so two waits per step suffice: before MFMA 0 (A0(i)) and before MFMA 4 (A1(i)), each allowing
+                // exactly the reads issued after the one it needs.
                 bf16x8 fa[2][2], fb[2][4];
-                auto load_b = [&](int kx, int s_) __attribute__((always_inline)) {
+                auto rd = [&](bf16x8& dst, unsigned addr, int imm) __attribute__((always_inline)) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
+                };
+                auto load_b1 = [&](int tap, int pxb) __attribute__((always_inline)) {
+                    int pb0 = pixb[pxb];
+                    asm volatile("" : "+v"(pb0));
+                    const int pix = pb0 + tg * HW5 + tap;
+                    rd(fb[tap & 1][pxb], lds0 + inbase + (unsigned)(pix << 6) + (q16 ^ (unsigned)((pix & 4) << 3)), 0);
+                };
+                auto load_a1 = [&](int i, int k) __attribute__((always_inline)) {       // step i = (tap i >> 2, cout quarter i & 3)
+                    const int off = tg * WST_BYTES5 + (i >> 2) * TAP_BYTES5 + (i & 3) * 2048 + k * 1024;
+                    rd(fa[i & 1][k], off < 32768 ? a_off : a_off_hi, off < 32768 ? off : off - 32768);
+                };
 #pragma unroll
-                    for (int pxb = 0; pxb < 4; ++pxb) {
-                        int pb0 = pixb[pxb];
-                        asm volatile("" : "+v"(pb0));
-                        const int pix = pb0 + tg * HW5 + kx;
-                        fb[s_][pxb] = *(const bf16x8*)(smem + inbase + (unsigned)(pix << 6) + (q16 ^ (unsigned)((pix & 4) << 3)));
-                    }
-                };
-                auto load_a = [&](int i, int s_) __attribute__((always_inline)) {       // step i = (tap i >> 2, cout quarter i & 3)
-                    const int kx = i >> 2, qt = i & 3;
-                    const unsigned char* wb = smem + tg * WST_BYTES5 + kx * TAP_BYTES5 + qt * 2048 + a_off;
-                    fa[s_][0] = *(const bf16x8*)(wb);
-                    fa[s_][1] = *(const bf16x8*)(wb + 1024);
-                };
-                load_b(0, 0);
-                load_a(0, 0);
+                for (int pxb = 0; pxb < 4; ++pxb) load_b1(0, pxb);
+                load_a1(0, 0);
+                load_a1(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    if (i + 1 < 12) {
-                        if (((i + 1) & 3) == 0) load_b((i + 1) >> 2, ((i + 1) >> 2) & 1);
-                        load_a(i + 1, (i + 1) & 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                     const int qt = i & 3, bs = (i >> 2) & 1;
+                    const bool a_next = i + 1 < 12;
+                    const bool b_cur = (i & 3) == 1 && (i >> 2) + 1 < 3;                     // this step issues the next tap's B
+                    const bool b_prev = i >= 1 && ((i - 1) & 3) == 1 && ((i - 1) >> 2) + 1 < 3;  // the previous step did
+                    const int n0 = 1 + (b_prev ? 4 : 0);
+                    const int n4 = (b_prev ? 4 : 0) + (a_next ? 2 : 0) + (b_cur ? 2 : 0);
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int pxb = 0; pxb < 4; ++pxb)
-                            acc[qt * 2 + k][pxb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][k], fb[bs][pxb], acc[qt * 2 + k][pxb], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int g = 0; g < 8; ++g) {
+                        const int k = g >> 2, pxb = g & 3;
+                        if (g == 0) {
+                            if (n0 == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[i & 1][0]), "+v"(fb[bs][0]));
+                            else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[i & 1][0]), "+v"(fb[bs][0]));
+                        } else if (g == 4) {
+                            if (n4 == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[i & 1][1]));
+                            else if (n4 == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[i & 1][1]));
+                            else if (n4 == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[i & 1][1]));
+                            else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[i & 1][1]));
+                            static_assert(true, "");
+                        } else if (k == 0) asm volatile("" : "+v"(fb[bs][pxb]));
+                        acc[qt * 2 + k][pxb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][k], fb[bs][pxb], acc[qt * 2 + k][pxb], 0, 0, 0);
+                        if (g < 2 && a_next) load_a1(i + 1, g);
+                        if (g >= 2 && g < 6 && b_cur) load_b1((i >> 2) + 1, g - 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+                if (w < 4) stage_issue();
                 wait_vm5(issued);
                 if (c == 3 && tg == 2) {
                     const int m = (int)cur_m;
@@ -281,7 +305,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
                     else epilogue(std::integral_constant<int, 2>{});
                 }
                 barrier5();
-            }
+            };
+            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 2>{});
         }
         cur_m = nxt_m; cur_t = nxt_t;
     }
