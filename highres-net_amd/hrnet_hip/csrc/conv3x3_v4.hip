@@ -58,6 +58,7 @@ __device__ __forceinline__ void wait_vm(int n) {          // counted wait; n is 
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
     // piece j, lane i -> LDS bytes j*1024 + i*16 = halo pixel j*16 + (i >> 2), physical 16-B chunk i & 3, which holds
     // logical chunk (i & 3) ^ ((pixel >> 2) & 3).
     const int n_in = w < (N_IN_DMA & 7) ? (N_IN_DMA >> 3) + 1 : (N_IN_DMA >> 3);
-    auto issue_in = [&](unsigned m, unsigned t, int c, int buf) __attribute__((always_inline)) {
+    auto issue_in = [&](unsigned m, unsigned t, int c, int buf, int jj_lo, int jj_hi) __attribute__((always_inline)) {
         const int ty = t / tiles_x;
         const int y0 = ty * T4_H, x0 = (t - ty * tiles_x) * T4_W;
         int pitch;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
 #pragma unroll
         for (int jj = 0; jj < (N_IN_DMA + 7) / 8; ++jj) {
             const int j = w + 8 * jj;
-            if (j < N_IN_DMA) {
+            if (j < N_IN_DMA && jj >= jj_lo && jj < jj_hi) {
                 const int pix = j * 16 + (lq >> 2);
                 const int lc = (lq & 3) ^ ((pix >> 2) & 3);
                 const int py = pix / HW4, px = pix - py * HW4;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
     // prologue: weights of stages 0 and 1, halo chunk 0 of the first tile
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    issue_in(cur_m, cur_t, 0, 0);
+    issue_in(cur_m, cur_t, 0, 0, 0, 8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_done_then_barrier4();
 
@@ -206,13 +207,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                 // The two waves of a SIMD (w, w+4) take the matrix pipe one after the other, so waves 4-7 issue their DMAs
                 // before their MFMAs (while waves 0-3 multiply) and waves 0-3 after theirs (while waves 4-7 multiply).
                 int issued = n_w;
-                if (tg == 0 && (c < 3 || more_tiles)) issued += n_in;
+                if (tg == 0 && (c < 3 || more_tiles)) issued += 3;               // halo pieces jj = 0..2 of the next chunk
+                if (tg == 1 && (c < 3 || more_tiles)) issued += n_in - 3;        // and jj = 3.. (2, wave 7: 1)
                 auto stage_issue = [&]() __attribute__((always_inline)) {
                     const int tg2 = (tg + 2) % 3, c2 = (c + (tg + 2) / 3) & 3;
                     issue_w(c2, tg2, tg2);
-                    if (tg == 0) {
-                        if (c < 3) issue_in(cur_m, cur_t, c + 1, (c + 1) & 1);
-                        else if (more_tiles) issue_in(nxt_m, nxt_t, 0, 0);
+                    if (tg < 2) {                                   // the next halo chunk, spread over two stages
+                        const int lo = tg == 0 ? 0 : 3, hi = tg == 0 ? 3 : 8;
+                        if (c < 3) issue_in(cur_m, cur_t, c + 1, (c + 1) & 1, lo, hi);
+                        else if (more_tiles) issue_in(nxt_m, nxt_t, 0, 0, lo, hi);
                     }
                 };
                 if (w >= 4) stage_issue();

@@ -44,6 +44,9 @@ __device__ __forceinline__ float raw_max5(float a, float b) {
 __device__ __forceinline__ void wait_vm5(int n) {
     switch (n) {
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
     };
     // halo chunk: piece j, lane i -> halo pixel j*16 + (i >> 2), physical chunk i & 3 = logical ^ swz5(pixel)
     const int n_in = w < (N_IN_DMA5 & 7) ? (N_IN_DMA5 >> 3) + 1 : (N_IN_DMA5 >> 3);
-    auto issue_in = [&](unsigned m, unsigned t, int c, int buf) __attribute__((always_inline)) {
+    auto issue_in = [&](unsigned m, unsigned t, int c, int buf, int jj_lo, int jj_hi) __attribute__((always_inline)) {
         const int ty = t / tiles_x;
         const int y0 = ty * T5_H, x0 = (t - ty * tiles_x) * T5_W;
         int pitch;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
 #pragma unroll
         for (int jj = 0; jj < (N_IN_DMA5 + 7) / 8; ++jj) {
             const int j = w + 8 * jj;
-            if (j < N_IN_DMA5) {
+            if (j < N_IN_DMA5 && jj >= jj_lo && jj < jj_hi) {
                 const int pix = j * 16 + (lq >> 2);
                 const int lc = (lq & 3) ^ swz5(pix);
                 const int py = pix / HW5, px = pix - py * HW5;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
     if (tid < 128) bias_lds[tid] = p.bias[tid];
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    issue_in(cur_m, cur_t, 0, 0);
+    issue_in(cur_m, cur_t, 0, 0, 0, 8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     barrier5();
 
@@ -161,13 +164,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v5_kernel(const ConvParams p) 
                 // DMAs in flight during this stage: weights of stage s+2, at tg == 0 the next halo chunk.  The two waves of a SIMD
                 // (w, w+4) take the matrix pipe one after the other: waves 4-7 issue before their MFMAs, waves 0-3 after theirs.
                 int issued = 3;
-                if (tg == 0 && (c < 3 || more_tiles)) issued += n_in;
+                if (tg == 0 && (c < 3 || more_tiles)) issued += 3;               // halo pieces jj = 0..2 of the next chunk
+                if (tg == 1 && (c < 3 || more_tiles)) issued += n_in - 3;        // and jj = 3.. (2, wave 7: 1)
                 auto stage_issue = [&]() __attribute__((always_inline)) {
                     const int tg2 = (tg + 2) % 3, c2 = (c + (tg + 2) / 3) & 3;
                     issue_w(c2, tg2, tg2);
-                    if (tg == 0) {
-                        if (c < 3) issue_in(cur_m, cur_t, c + 1, (c + 1) & 1);
-                        else if (more_tiles) issue_in(nxt_m, nxt_t, 0, 0);
+                    if (tg < 2) {                                   // the next halo chunk, spread over two stages
+                        const int lo = tg == 0 ? 0 : 3, hi = tg == 0 ? 3 : 8;
+                        if (c < 3) issue_in(cur_m, cur_t, c + 1, (c + 1) & 1, lo, hi);
+                        else if (more_tiles) issue_in(nxt_m, nxt_t, 0, 0, lo, hi);
                     }
                 };
                 if (w >= 4) stage_issue();
