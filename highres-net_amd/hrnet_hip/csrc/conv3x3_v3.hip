@@ -523,10 +523,10 @@ int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t st
     }
     if (cin == 128) {
         // 512-pixel-tile, 8-MFMA-wave, LDS-DMA kernel (conv3x3_v4.hip) for the fusion level's three layers;
-        // HRN_CONV_V4 = 0: off, 1 (default): 128 -> 128 only, 2: 128 -> 64 as well.  For 128 -> 64 the two kernels measure the
-        // same (0.57 ms per launch at c3: that layer moves 512 B per pixel for 147 kFLOP), so it stays on v3.
+        // HRN_CONV_V4 = 0: off, 1: 128 -> 128 only, 2 (default): 128 -> 64 as well (0.56 ms per launch at c3 against 0.58 on v3
+        // since the hand-issued fragment reads and the staggered DMA issue)
         static int v4 = -1;
-        if (v4 < 0) { const char* e = getenv("HRN_CONV_V4"); v4 = e ? atoi(e) : 1; }
+        if (v4 < 0) { const char* e = getenv("HRN_CONV_V4"); v4 = e ? atoi(e) : 2; }
         if (v4 >= (cout == 64 ? 2 : 1)) { const int rc = hrn_launch_conv3x3_v4(cout, p, stream); if (rc != -100) return rc; }
     }
     if (cin == 128 && cout == 64) return offload ? launch_v3<128, 64, true>(p, stream) : launch_v3<128, 64, false>(p, stream);
