@@ -48,6 +48,28 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// 4 x 4 transpose of 16-byte items across each quad of lanes (see conv3x3_r64.hip)
+__device__ __forceinline__ void quad_transpose4(u32x4 (&x)[4], bool b0, bool b1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int p = 0; p < 4; p += 2) {
+            const unsigned a = x[p][d], b = x[p + 1][d];
+            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);
+            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xF, 0xF, true);
+            x[p][d] = b0 ? ra : a;
+            x[p + 1][d] = b0 ? b : rb;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned a = x[p][d], b = x[p + 2][d];
+            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true);
+            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xF, 0xF, true);
+            x[p][d] = b1 ? ra : a;
+            x[p + 2][d] = b1 ? b : rb;
+        }
+    }
+}
 __device__ __forceinline__ float raw_max4(float a, float b) {
     float y;
     asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
@@ -315,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
 #pragma unroll
                             for (int pr = 0; pr < NPR; ++pr) {          // cout blocks (2pr, 2pr+1) -> channels 64pr + 32hh ..
                                 u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * OPIX + pr * 128) + lane_out);
+                                u32x4 uu[4];                             // COUT = 64: the group's four pieces, stored as whole lines
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
                                     float xa[4], xb[4];
@@ -351,7 +374,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                                         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pack2_bf16(xa[2], xa[3]), pack2_bf16(xb[2], xb[3]), false, false);
                                         u[0] = s0[0]; u[1] = s1[0]; u[2] = s0[1]; u[3] = s1[1];
                                     }
-                                    if (ok) op[g] = u;
+                                    if (COUT == 64) uu[g] = u;
+                                    else if (ok) op[g] = u;
+                                }
+                                if (COUT == 64) {   // registers to spare here: quad transpose -> every store instruction writes whole lines
+                                    quad_transpose4(uu, (lane & 1) != 0, (lane & 2) != 0);
+                                    unsigned char* oq = outp + (unsigned)(((2 * w + pb) * W + (r & ~3)) * OPIX + pr * 128 + hh * 64 + (r & 3) * 16);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (gy < H && x0 + (r & ~3) + j < W) *(u32x4*)(oq + j * OPIX) = uu[j];
                                 }
                             }
                         }
