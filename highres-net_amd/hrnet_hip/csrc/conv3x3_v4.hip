@@ -375,7 +375,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                                         u[0] = s0[0]; u[1] = s1[0]; u[2] = s0[1]; u[3] = s1[1];
                                     }
                                     if (COUT == 64) uu[g] = u;
-                                    else if (ok) op[g] = u;
+                                    else {
+                                        // COUT = 128 has no registers for the quad transpose: pieces are exchanged between the two
+                                        // lanes of a pair instead (even lane: piece g of both pixels, odd lane: piece g+1), so that a
+                                        // pair writes 32 contiguous bytes and an instruction touches 16 lines, not 32
+                                        uu[g & 1] = u;
+                                        if (g & 1) {
+                                            const bool odd = (lane & 1) != 0;
+                                            u32x4 s0, s1;
+#pragma unroll
+                                            for (int d = 0; d < 4; ++d) {
+                                                const unsigned a = uu[0][d], b = uu[1][d];
+                                                const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);
+                                                const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xF, 0xF, true);
+                                                s0[d] = odd ? ra : a;           // even: own piece g-1 | odd: the even pixel's piece g
+                                                s1[d] = odd ? b : rb;           // even: the odd pixel's piece g-1 | odd: own piece g
+                                            }
+                                            // even lane -> piece g-1, odd lane -> piece g; store 0 goes to the even pixel, store 1 to the odd one
+                                            unsigned char* oe = outp + (unsigned)(((2 * w + pb) * W + (r & ~1)) * OPIX + pr * 128 + hh * 64 + (g - 1 + (lane & 1)) * 16);
+                                            if (gy < H && x0 + (r & ~1) < W) *(u32x4*)oe = s0;
+                                            if (gy < H && x0 + (r | 1) < W) *(u32x4*)(oe + OPIX) = s1;
+                                        }
+                                    }
                                 }
                                 if (COUT == 64) {   // registers to spare here: quad transpose -> every store instruction writes whole lines
                                     quad_transpose4(uu, (lane & 1) != 0, (lane & 2) != 0);
