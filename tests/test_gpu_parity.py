@@ -243,10 +243,11 @@ def test_errors_are_loud():
     m2.precision = "fp32"
 
 
-@pytest.mark.parametrize("S,V", [(8, 2), (20, 3), (40, 5), (72, 4), (100, 2)])
+@pytest.mark.parametrize("S,V", [(8, 2), (18, 2), (20, 3), (27, 3), (40, 5), (50, 2), (72, 4), (100, 2)])
 def test_bf16_kernels_on_awkward_sizes_vs_fp32_path(S, V):
     """Image sides that are no multiple of any tile (conv3x3_v4: 16 x 32, conv3x3_r64 / v3: 8 x 32; LDS-DMA halo pieces that end
-    mid-row, EXEC-masked last pieces, partial store rows): the bf16 kernels against the exact-fp32 path on the same inputs."""
+    mid-row, EXEC-masked last pieces, partial store rows; widths that split a lane pair (27) or a lane quad (18, 50) of the
+    coalescing lane exchanges in the epilogues): the bf16 kernels against the exact-fp32 path on the same inputs."""
     lrs, alphas = synth.fast_batch(40 + S, 2, V, S)
     x, a = util.dev(lrs), util.dev(alphas)
     with torch.no_grad():
