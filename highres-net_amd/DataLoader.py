@@ -149,3 +149,100 @@ class ImagesetDataset(Dataset):
         io_binding.collate([p["lr_paths"] for p in plans], [p["hr"] for p in plans] if have_hr else None, [p["sm"] for p in plans],
                            min_L=min_L, lr_size=side, patch=patch, corners=[p["corner"] for p in plans], out=out, n_threads=n_threads)
         return out["lrs"], out["alphas"], out["hrs"] if have_hr else [], out["maps"], [p["name"] for p in plans]
+
+
+class BatchPrefetcher:
+    """Iterate over whole batches of an ImagesetDataset with the next batch's decode and host-to-device copy running
+    while the caller computes on the current one.
+
+        for lrs, alphas, hrs, hr_maps, names in BatchPrefetcher(dataset, batches, min_L, device="cuda"):
+            ...
+
+    `batches` is a sequence of index lists (what a BatchSampler yields).  A worker thread decodes batch n+1 with
+    `load_batch(pin_memory=True)` - the native thread pool does the PNG work - and, for a CUDA device, enqueues the copies
+    on a private stream; the consumer's stream waits on that copy's event only when it takes the batch, so PCIe traffic and
+    decode overlap the kernels of batch n.  Tensors are handed over with `record_stream`, i.e. their memory is not reused
+    before the consumer's queued work has finished.  With device=None or "cpu" it is a plain background decoder.
+    Errors raised by the worker are re-raised in the consumer at the batch they belong to."""
+
+    def __init__(self, dataset, batches, min_L, device=None, depth=2, n_threads=0):
+        import queue
+        import threading
+        self.dataset, self.batches, self.min_L = dataset, [list(b) for b in batches], int(min_L)
+        self.device = torch.device(device) if device is not None else None
+        self.on_gpu = self.device is not None and self.device.type == "cuda"
+        if self.on_gpu and not torch.cuda.is_available():
+            raise RuntimeError("BatchPrefetcher: device is cuda but no GPU is available")
+        self.n_threads = n_threads
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._work, name="hrn-batch-prefetch", daemon=True)
+        self._started = False
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _work(self):
+        stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        try:
+            for idx in self.batches:
+                if self._stop.is_set():
+                    return
+                try:
+                    lrs, alphas, hrs, maps, names = self.dataset.load_batch(idx, self.min_L, pin_memory=self.on_gpu,
+                                                                            n_threads=self.n_threads)
+                    event = None
+                    if self.on_gpu:
+                        with torch.cuda.stream(stream):
+                            lrs = lrs.to(self.device, non_blocking=True)
+                            alphas = alphas.to(self.device, non_blocking=True)
+                            maps = maps.to(self.device, non_blocking=True)
+                            if isinstance(hrs, torch.Tensor):
+                                hrs = hrs.to(self.device, non_blocking=True)
+                            event = torch.cuda.Event()
+                            event.record(stream)
+                    item = ("ok", (lrs, alphas, hrs, maps, names), event, stream)
+                except Exception as exc:                     # handed to the consumer, in order
+                    item = ("err", exc, None, None)
+                while not self._stop.is_set():
+                    try:
+                        self._q.put(item, timeout=0.1)
+                        break
+                    except Exception:
+                        continue
+                if item[0] == "err":
+                    return
+        finally:
+            while not self._stop.is_set():
+                try:
+                    self._q.put(("end", None, None, None), timeout=0.1)
+                    break
+                except Exception:
+                    continue
+
+    def __iter__(self):
+        if self._started:
+            raise RuntimeError("BatchPrefetcher can be iterated once")
+        self._started = True
+        self._thread.start()
+        try:
+            while True:
+                kind, payload, event, stream = self._q.get()
+                if kind == "end":
+                    return
+                if kind == "err":
+                    raise payload
+                if event is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(event)
+                    for t in payload[:4]:
+                        if isinstance(t, torch.Tensor):
+                            t.record_stream(cur)
+                yield payload
+        finally:
+            self.close()
+
+    def close(self):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(timeout=5.0)

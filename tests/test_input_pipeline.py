@@ -182,3 +182,51 @@ def test_io_abi_matches_header():
     lib = io_binding.load_library()
     for name in declared:
         assert hasattr(lib, name)
+
+
+def test_batch_prefetcher_cpu(tmp_path):
+    """Background decode of whole batches: same tensors as load_batch, in order; worker errors surface in the consumer."""
+    dirs = [_write_imageset(str(tmp_path), f"imgset{i:04d}", n, seed=20 + i) for i, n in enumerate((4, 9, 6, 5))]
+    ds = DL.ImagesetDataset(dirs, {"create_patches": True, "patch_size": 64}, seed=11, top_k=-1)
+    batches = [[0, 1], [2, 3], [1]]
+    want = [ds.load_batch(b, min_L=8) for b in batches]
+    got = list(DL.BatchPrefetcher(ds, batches, min_L=8, device="cpu", depth=1))
+    assert len(got) == 3
+    for g, w in zip(got, want):
+        assert all(torch.equal(a, b) for a, b in zip(g[:4], w[:4])) and g[4] == w[4]
+    # an early exit stops the worker; a second iteration is refused
+    pf = DL.BatchPrefetcher(ds, batches * 4, min_L=8)
+    it = iter(pf)
+    next(it)
+    it.close()
+    assert not pf._thread.is_alive()
+    with pytest.raises(RuntimeError, match="once"):
+        iter(pf).__next__()
+    # a broken imageset raises at its batch, after the good ones
+    os.remove(os.path.join(dirs[3], "SM.png"))
+    ds_bad = DL.ImagesetDataset(dirs, {"create_patches": True, "patch_size": 64}, seed=11, top_k=-1)
+    seen = 0
+    with pytest.raises(Exception):
+        for _ in DL.BatchPrefetcher(ds_bad, [[0, 1], [2, 3]], min_L=8):
+            seen += 1
+    assert seen == 1
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no GPU"):
+            DL.BatchPrefetcher(ds, batches, min_L=8, device="cuda")
+
+
+@pytest.mark.gpu
+def test_batch_prefetcher_gpu(tmp_path):
+    """Copies on the prefetcher's stream are ordered before the consumer's kernels: device batches equal the host ones."""
+    dirs = [_write_imageset(str(tmp_path), f"imgset{i:04d}", n, seed=30 + i) for i, n in enumerate((4, 9, 6, 5))]
+    ds = DL.ImagesetDataset(dirs, {"create_patches": True, "patch_size": 64}, seed=2, top_k=-1)
+    batches = [[0, 1], [2, 3], [3, 0], [1, 2]] * 3
+    want = [ds.load_batch(b, min_L=8) for b in batches]
+    n = 0
+    for g, w in zip(DL.BatchPrefetcher(ds, batches, min_L=8, device="cuda"), want):
+        assert g[0].is_cuda and g[1].is_cuda and g[3].is_cuda
+        s = (g[0].sum() + g[2].sum()).item()                 # consumer-stream work on the fresh tensors
+        assert abs(s - (w[0].sum() + w[2].sum()).item()) <= 1e-3 * abs(s) + 1e-3
+        assert torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1].cpu(), w[1]) and torch.equal(g[2].cpu(), w[2]) and torch.equal(g[3].cpu(), w[3])
+        n += 1
+    assert n == len(batches)
