@@ -50,6 +50,33 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
+// 4 x 4 transpose of 16-byte items across each quad of lanes (4k .. 4k+3): x[j] of lane i <- x[i] of lane j (b0 / b1 = bit 0 /
+// bit 1 of the lane id).  Two butterfly stages of v_mov_dpp quad_perm + v_cndmask per dword, 64 VALU per call.  The conv
+// epilogues use it to turn "a lane owns 64 contiguous bytes of its own pixel" (one store instruction = 64 pieces of 16 bytes
+// in 32 different 128-byte lines) into "the four lanes of a quad own the four pieces of one pixel" (8 whole lines per store
+// instruction, together with the other half-wave) where they have the registers and the VALU time for it.
+__device__ __forceinline__ void quad_transpose(u32x4 (&x)[4], bool b0, bool b1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int p = 0; p < 4; p += 2) {
+            const unsigned a = x[p][d], b = x[p + 1][d];
+            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xF, 0xF, true);
+            x[p][d] = b0 ? ra : a;
+            x[p + 1][d] = b0 ? b : rb;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned a = x[p][d], b = x[p + 2][d];
+            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xF, 0xF, true);
+            x[p][d] = b1 ? ra : a;
+            x[p + 2][d] = b1 ? b : rb;
+        }
+    }
+}
+
 template <int DT> struct ElemOf;
 template <> struct ElemOf<HRN_F32>  { typedef float type;          static constexpr int size = 4; };
 template <> struct ElemOf<HRN_BF16> { typedef unsigned short type; static constexpr int size = 2; };

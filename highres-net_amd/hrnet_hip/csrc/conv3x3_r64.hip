@@ -48,32 +48,6 @@ __device__ __forceinline__ float raw_max(float a, float b) {
 
 __device__ __attribute__((aligned(16))) unsigned hrn_r64_zero16[4];
 
-// 4 x 4 transpose of 16-byte items across each quad of lanes (4k .. 4k+3): x[j] of lane i <- x[i] of lane j.  Two butterfly
-// stages of v_mov_dpp quad_perm + v_cndmask per dword.  Turns "a lane owns 64 contiguous bytes of its own pixel" (one store
-// instruction = 64 pieces of 16 bytes in 32 different 128-byte lines) into "the four lanes of a quad own the four pieces of
-// one pixel" (8 whole lines per store instruction, together with the other half-wave).
-__device__ __forceinline__ void quad_transpose(u32x4 (&x)[4], bool b0, bool b1) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-#pragma unroll
-        for (int p = 0; p < 4; p += 2) {
-            const unsigned a = x[p][d], b = x[p + 1][d];
-            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);
-            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xF, 0xF, true);
-            x[p][d] = b0 ? ra : a;
-            x[p + 1][d] = b0 ? b : rb;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const unsigned a = x[p][d], b = x[p + 2][d];
-            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true);
-            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xF, 0xF, true);
-            x[p][d] = b1 ? ra : a;
-            x[p + 2][d] = b1 ? b : rb;
-        }
-    }
-}
-
 template <bool RES>
 __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -48,28 +48,6 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-// 4 x 4 transpose of 16-byte items across each quad of lanes (see conv3x3_r64.hip)
-__device__ __forceinline__ void quad_transpose4(u32x4 (&x)[4], bool b0, bool b1) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-#pragma unroll
-        for (int p = 0; p < 4; p += 2) {
-            const unsigned a = x[p][d], b = x[p + 1][d];
-            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);
-            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xF, 0xF, true);
-            x[p][d] = b0 ? ra : a;
-            x[p + 1][d] = b0 ? b : rb;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const unsigned a = x[p][d], b = x[p + 2][d];
-            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true);
-            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xF, 0xF, true);
-            x[p][d] = b1 ? ra : a;
-            x[p + 2][d] = b1 ? b : rb;
-        }
-    }
-}
 __device__ __forceinline__ float raw_max4(float a, float b) {
     float y;
     asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
@@ -194,7 +172,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
             const int pix = (2 * w + row) * HW4 + r + kx;
             b_off[row][kx] = lds0 + (unsigned)(OFF_IN + pix * 64 + (((hh) ^ ((pix >> 2) & 3)) << 4));
         }
-    const unsigned lane_out = (unsigned)((2 * w * W + r) * OPIX + hh * 64);    // byte offset of (row 2w, col r, half hh) in a tile
 
     f32x16 acc[NCB][2];                                     // [cout block][pixel row]
 
@@ -326,18 +303,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                         if (RESM == 3 && p.alphas) res_alpha = p.alphas[(size_t)ob * p.alpha_vs + (p.pair_last - oi)];
                     }
                     unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * OPIX;
-                    const int gx = x0 + r;
                     if (RES) res_fetch(1);                      // pixel row 1's residual: in flight while row 0 is finished
                     auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
                         constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
                         for (int pb = 0; pb < 2; ++pb) {
                             const int gy = y0 + 2 * w + pb;
-                            const bool ok = gy < H && gx < W;
 #pragma unroll
                             for (int pr = 0; pr < NPR; ++pr) {          // cout blocks (2pr, 2pr+1) -> channels 64pr + 32hh ..
-                                u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * OPIX + pr * 128) + lane_out);
-                                u32x4 uu[4];                             // COUT = 64: the group's four pieces, stored as whole lines
+                                u32x4 uu[4];                             // COUT = 64: the group's four pieces | COUT = 128: two at a time
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
                                     float xa[4], xb[4];
@@ -399,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v4_kernel(const ConvParams p) 
                                     }
                                 }
                                 if (COUT == 64) {   // registers to spare here: quad transpose -> every store instruction writes whole lines
-                                    quad_transpose4(uu, (lane & 1) != 0, (lane & 2) != 0);
+                                    quad_transpose(uu, (lane & 1) != 0, (lane & 2) != 0);
                                     unsigned char* oq = outp + (unsigned)(((2 * w + pb) * W + (r & ~3)) * OPIX + pr * 128 + hh * 64 + (r & 3) * 16);
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
