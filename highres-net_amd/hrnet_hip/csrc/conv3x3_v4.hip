@@ -13,8 +13,14 @@
 //   * K is walked as 4 chunks of 32 input channels (64 B per pixel) x 3 tap rows: one stage = 3 taps x 32 channels
 //     (24 KB of weights for COUT = 128, ring of 3) against a double-buffered 18 x 34-pixel halo chunk (39 KB each);
 //     ONE barrier per stage; stage s+2's weights and the next chunk's halo are in flight while stage s multiplies;
+//   * fragment reads are hand-written ds_read_b128 with counted lgkmcnt waits, one per MFMA gap (hipcc stops counting LDS
+//     waits in a kernel with LDS-DMA); the two waves of a SIMD (w, w+4) run their MFMAs one after the other, so waves 4-7
+//     issue their DMAs before and waves 0-3 after their MFMAs; the next halo chunk's pieces go out over two stages;
 //   * epilogue from the accumulators (bias pre-loaded into them, PReLU, v_permlane32_swap -> 64 contiguous bytes per lane,
-//     residual, one bf16 rounding, 16-byte stores); the residual's first half is fetched before the tile's last stage.
+//     residual, one bf16 rounding, 16-byte stores); the residual's first half is fetched before the tile's last stage;
+//     before the stores lanes exchange pieces so that an instruction touches fewer lines (COUT = 64: quad transpose, whole
+//     128-byte lines; COUT = 128: lane pairs, 32 contiguous bytes - all that fits beside 128 accumulators).
+//   Measurements behind these choices: profiles/r01_final_inkernel_stamps.txt.
 // RESM: 0 no residual | 2 the pair gather z (COUT = 128: t2 = z + PReLU(conv(t1))) | 3 s_i + alpha_partner * f into the
 // view stack (COUT = 64, HRNet.py:123-131).
 // LDS (COUT = 128): 3 x 24,576 (weights) + 2 x 39,936 (halo) + 512 (bias) = 154,112 B.
