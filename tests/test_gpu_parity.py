@@ -284,3 +284,28 @@ def test_forward_is_graph_capturable():
         replayed = out.clone()
         eager2 = m(x, a)
     assert torch.equal(replayed, eager2) and not torch.equal(eager1, eager2)
+
+
+@pytest.mark.parametrize("S,V", [(18, 2), (27, 3), (50, 4), (100, 2)])
+def test_bf16_stages_on_ragged_widths_vs_fp32_path(S, V):
+    """Stage by stage (encoder = conv3x3_r64, fusion = conv3x3_v4 / v5) at widths that cut lane pairs / quads of the epilogues'
+    coalescing exchanges and leave partial tiles: every pixel of the bf16 stage outputs against the exact-fp32 path's, so that a
+    mis-addressed piece at an image edge cannot hide in a whole-image PSNR."""
+    lrs, alphas = synth.fast_batch(900 + S, 2, V, S)
+    x, a = util.dev(lrs), util.dev(alphas)
+    m32, m16 = util.hip_hrnet("fp32"), util.hip_hrnet("bf16")
+    with torch.no_grad():
+        e32, e16 = m32.encode_views(x), m16.encode_views(x)
+        assert e16.shape == e32.shape == (2, V, S, S, 64)
+        scale = float(e32.abs().max())
+        err = (e16.float() - e32.float()).abs()
+        assert float(err.max()) <= 3e-2 * scale, (float(err.max()), scale)
+        # worst pixel per column must not stand out at the right edge (a wrong piece would be off by O(scale))
+        col = err.amax(dim=(0, 1, 2, 4))
+        assert float(col[-4:].max()) <= 3.0 * float(col[: max(4, S - 4)].max()) + 1e-3 * scale
+        f32, f16 = m32.fuse_views(e32, a), m16.fuse_views(e16, a)
+        scale = float(f32.abs().max())
+        err = (f16.float() - f32.float()).abs()
+        assert float(err.max()) <= 4e-2 * scale, (float(err.max()), scale)
+        col = err.amax(dim=(0, 1, 3))
+        assert float(col[-4:].max()) <= 3.0 * float(col[: max(4, S - 4)].max()) + 1e-3 * scale
