@@ -309,3 +309,15 @@ def test_bf16_stages_on_ragged_widths_vs_fp32_path(S, V):
         assert float(err.max()) <= 4e-2 * scale, (float(err.max()), scale)
         col = err.amax(dim=(0, 1, 3))
         assert float(col[-4:].max()) <= 3.0 * float(col[: max(4, S - 4)].max()) + 1e-3 * scale
+
+
+def test_large_image_bf16_vs_fp32_path():
+    """BASELINE config 5's image size (512 x 512 -> 1536 x 1536) on a small batch: many tile rows / columns per image, larger in-image
+    byte offsets; the bf16 kernels against the exact-fp32 path."""
+    lrs, alphas = synth.fast_batch(4242, 1, 3, 512)
+    x, a = util.dev(lrs), util.dev(alphas)
+    with torch.no_grad():
+        ref = util.hip_hrnet("fp32")(x, a).cpu().numpy()
+        got = util.hip_hrnet("bf16")(x, a).cpu().numpy()
+    assert got.shape == (1, 1, 1536, 1536) and np.isfinite(got).all()
+    assert util.rel_err(got, ref) <= BF16_REL and util.psnr_db(got, ref) >= BF16_PSNR
