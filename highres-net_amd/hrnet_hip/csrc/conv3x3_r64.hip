@@ -94,10 +94,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
     // holds logical chunk (i & 7) ^ ((pixel >> 1) & 7).  Out-of-image pixels are read from a zero line; the half-empty
     // last piece is EXEC-masked.  The geometry is recomputed from an opaque copy of the lane id so that it does not sit
     // in registers through the MFMA phase.
+    // Residual-free variant: FULL tiles whose halo addresses all lie inside the tensor take a fast form - per-lane byte
+    // offsets from the halo origin precomputed once (11 registers), no bounds tests, no zero-line select; pixels outside the
+    // image are then zeroed in LDS (fix_borders) by the wave that fetched them, after its DMAs have landed.  The residual
+    // variant has no registers to spare for the offsets (measured slower) and keeps the general form.
+    unsigned voff[11], cm_lo = 0, cm_hi = 0;                // cm: 4 bits per piece: pixel in top row | bottom row | left | right column
+    if (!RES) {
+#pragma unroll
+        for (int jj = 0; jj < 11; ++jj) {
+            const int j = tw + 4 * jj;
+            const int pix = j * 8 + (lane >> 3);
+            const int py = pix / HALO_W, px = pix - py * HALO_W;
+            voff[jj] = (unsigned)((py * W + px) * 128 + (((lane & 7) ^ ((pix >> 1) & 7)) << 4));
+            unsigned cls = (py == 0 ? 1u : 0u) | (py == HALO_H - 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == HALO_W - 1 ? 8u : 0u);
+            if (pix >= HALO_H * HALO_W) cls = 0;
+            if (jj < 8) cm_lo |= cls << (4 * jj); else cm_hi |= cls << (4 * (jj - 8));
+        }
+    }
+    unsigned pend_F = 0;                                    // border flags of the tile whose halo is in flight (fast form only)
     auto issue = [&](unsigned m, unsigned t) __attribute__((always_inline)) {
         const int ty = t / tiles_x;
         const int y0 = ty * CONV_TILE_H, x0 = (t - ty * tiles_x) * CONV_TILE_W;
         const unsigned char* base = (const unsigned char*)p.in + (size_t)m * hw * 128;     // uniform: image base
+        const bool fast = !RES && y0 + CONV_TILE_H <= H && x0 + CONV_TILE_W <= W && (m > 0 || y0 > 0) &&
+                          ((int)m + 1 < p.M || (size_t)(y0 + CONV_TILE_H) * W + x0 + CONV_TILE_W < hw);
+        pend_F = 0;
+        if (fast) {
+            const unsigned char* hb = base + ((long)(y0 - 1) * W + (x0 - 1)) * 128;
+#pragma unroll
+            for (int jj = 0; jj < 11; ++jj) {
+                const int j = tw + 4 * jj;
+                if (j < 43) {
+                    if (jj < 10 || j * 8 + (lane >> 3) < HALO_H * HALO_W)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + voff[jj]),
+                                                         (__attribute__((address_space(3))) void*)(in_lds + j * 1024), 16, 0, 0);
+                }
+            }
+            pend_F = (y0 == 0 ? 1u : 0u) | (y0 + CONV_TILE_H == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + CONV_TILE_W == W ? 8u : 0u);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         int lq = lane;
         asm volatile("" : "+v"(lq));
 #pragma unroll
@@ -116,6 +152,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fix_borders = [&]() __attribute__((always_inline)) {
+        if (!RES && pend_F) {
+            const unsigned fm = pend_F * 0x11111111u;
+            const unsigned hit_lo = cm_lo & fm, hit_hi = cm_hi & fm;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int jj = 0; jj < 11; ++jj) {
+                const int j = tw + 4 * jj;
+                if (j < 43) {
+                    const unsigned h = jj < 8 ? (hit_lo >> (4 * jj)) & 15u : (hit_hi >> (4 * (jj - 8))) & 15u;
+                    if (h) *(u32x4*)(in_lds + j * 1024 + lane * 16) = z;
+                }
+            }
+        }
     };
 
     const bool has_slope = p.slope != nullptr;
@@ -328,10 +379,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
             else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        fix_borders();
     };
 
     if (nmine > 0) issue(cur_m, cur_t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fix_borders();
     lds_done_then_barrier();                                // weights, bias, both teams' first halo tiles
 
     // phase ph: team 0 is at step q = ph, team 1 at q = ph - 1; even q = ON (tile q/2), odd q = OFF (tile (q-1)/2)
