@@ -21,6 +21,12 @@
 // VALU / VMEM work, so neither the epilogue nor the input staging costs MFMA time.  No ordinary global load is issued in
 // the OFF phase: beside an LDS-DMA in flight hipcc waits vmcnt(0) for any of them, which would drain the DMAs early.
 // Same math / layouts / packed weights / persistent XCD-windowed tile walk as the other conv kernels.
+// Measured in-kernel (profiles/r01_final_inkernel_stamps.txt): ON 5.4 k cycles for 4.6 k of matrix pipe since the fragment
+// reads are hand-issued with counted lgkmcnt waits (multiply()); the OFF phase (6.3 k, 8.2 k with the residual) is bound by
+// the CU's vector-memory pipe - 44 DMA + 32 store (+ 32 residual load) wave-instructions at ~60-70 cycles each.  Without
+// residual, full tiles take their halo from precomputed lane offsets (issue(), fix_borders()) and store whole 128-byte
+// lines through a quad transpose; with the residual neither pays (registers / VALU time) and it runs at 75 % of the
+// achievable HBM bandwidth anyway.
 #include <type_traits>
 #include "conv3x3.h"
 
