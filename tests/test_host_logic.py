@@ -87,3 +87,22 @@ def test_conv_pack_index_math(cin, cout, es):
     flat = (co * cin + ci) * 9 + tap
     assert np.array_equal(np.sort(flat), np.arange(total))
     assert step.max() + 1 == (cin // kb) * 9 * nhalf
+
+
+def test_stamp_instrumenters_still_apply(tmp_path):
+    """tools/stamps/instr_*.py patch s_memtime stamps into copies of the conv kernels by text anchors (profiles/
+    r01_final_inkernel_stamps.txt was made with them): every anchor must still exist in the current sources."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "highres-net_amd", "hrnet_hip", "csrc")
+    for which, fn, marker in (("r64", "conv3x3_r64.hip", "hrn_dbg_read_stamps"), ("v4", "conv3x3_v4.hip", "hrn_dbg_read_stamps_v4"),
+                              ("v5", "conv3x3_v5.hip", "hrn_dbg_read_stamps_v5")):
+        d = tmp_path / which
+        d.mkdir()
+        shutil.copy(os.path.join(csrc, fn), d / fn)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "stamps", f"instr_{which}.py"), str(d)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-800:]
+        text = (d / fn).read_text()
+        assert marker in text and text.count("STAMP(") >= 7

@@ -23,7 +23,7 @@ rep("    const bool has_slope = p.slope != nullptr;",
 rep("        constexpr int NK = 36;", "        STAMP(6);\n        constexpr int NK = 36;")
 rep("        if (more) issue(cur_m, cur_t);                      // in flight while the epilogue runs", "        if (more && !(abl & 2)) issue(cur_m, cur_t);\n        STAMP(3);")
 rep("        {   // the halo DMAs were issued before this tile's stores", "        STAMP(4);\n        {   // the halo DMAs were issued before this tile's stores")
-rep("            else asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        }\n    };", "            else asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        }\n        STAMP(5);\n    };")
+rep("        fix_borders();\n    };", "        fix_borders();\n        STAMP(5);\n    };")
 rep("    for (int ph = 0; ph <= ntl; ++ph) {\n        const int q = ph - team;", "    for (int ph = 0; ph <= ntl; ++ph) {\n        cur_ph = ph;\n        STAMP(0);\n        const int q = ph - team;")
 rep("        if (ph < ntl) lds_done_then_barrier();\n    }\n}", """        STAMP(1);
         if (ph < ntl) lds_done_then_barrier();
