@@ -8,8 +8,9 @@ PNG decode, crop, uint16 -> float32, padding - runs in libhrnet_io.so (`hrnet_hi
 surface, `ImagesetDataset.load_batch()` collates a whole batch straight into (optionally pinned) buffers on a thread pool.
 """
 from collections import OrderedDict
-import glob
-from os.path import basename, exists, isfile, join
+import operator
+import os
+import re
 
 import numpy as np
 import torch
@@ -17,121 +18,134 @@ from torch.utils.data import Dataset
 
 from hrnet_hip import io_binding
 
+_QM_FILE = re.compile(r"^QM(.*)\.png$", re.S)       # one quality map per LR view; the text between "QM" and ".png" is the view id
+
 
 def get_patch(img, x, y, size=32):
-    """img[..., x:x+size, y:y+size]: x is the row corner, y the column corner (the reference's naming)."""
-    return img[..., x:(x + size), y:(y + size)]
+    """Square window of the two trailing axes of `img`: rows x .. x+size-1, columns y .. y+size-1 (x is the ROW corner, as in
+    the reference); leading axes (e.g. the view axis of an LR stack) are kept."""
+    rows, cols = slice(x, x + size), slice(y, y + size)
+    return img[..., rows, cols]
 
 
 class ImageSet(OrderedDict):
-    """OrderedDict grouping the assets of an imageset, with the reference's pretty-print."""
+    """The assets of one imageset (name, lr, hr, hr_map, clearances) as an ordered mapping whose repr lists one asset per line:
+    key right-aligned to 10 columns, then shape / class / dtype for arrays and tensors, class and value for anything else."""
 
     def __repr__(self):
-        info = f"{'name':>10} : {self['name']}"
-        for name, v in self.items():
-            if hasattr(v, "shape"):
-                info += f"\n{name:>10} : {v.shape} {v.__class__.__name__} ({v.dtype})"
-            else:
-                info += f"\n{name:>10} : {v.__class__.__name__} ({v})"
-        return info
+        def describe(value):
+            kind = type(value).__name__
+            if hasattr(value, "shape"):
+                return f"{value.shape} {kind} ({value.dtype})"
+            return f"{kind} ({value})"
+
+        lines = ["name".rjust(10) + f" : {self['name']}"]
+        lines.extend(key.rjust(10) + " : " + describe(value) for key, value in self.items())
+        return "\n".join(lines)
 
 
 def sample_clearest(clearances, n=None, beta=50, seed=None):
-    """Indices of `n` views drawn without replacement with probability softmax(beta * clearance / max clearance)."""
+    """Draw `n` distinct view indices with probability softmax(beta * clearance / max clearance): beta = 0 is uniform, large beta
+    approaches "the n clearest".  RNG contract (shared with the reference so that a seeded run picks the same views): an optional
+    `np.random.seed(seed)`, then exactly one `np.random.choice(..., replace=False)` over the weights below, computed in the same
+    floating-point order ((beta * c) / max c, exp, normalise)."""
     if seed is not None:
         np.random.seed(seed)
-    e_c = np.exp(beta * clearances / clearances.max())
-    p = e_c / e_c.sum()
-    return np.random.choice(range(len(p)), size=n, p=p, replace=False)
+    weights = np.exp(np.divide(np.multiply(beta, clearances), np.max(clearances)))
+    return np.random.choice(len(weights), size=n, replace=False, p=weights / np.sum(weights))
 
 
-def _select(imset_dir, top_k, beta, seed):
-    """View names in use order + their clearances (DataLoader.py:97-119)."""
-    idx_names = np.sort(np.array([basename(path)[2:-4] for path in glob.glob(join(imset_dir, "QM*.png"))]))
-    if not isfile(join(imset_dir, "clearance.npy")):
+def _views_in_use_order(imset_dir, top_k, beta, seed):
+    """(view ids, clearances) of an imageset in the order the model consumes them: `top_k` > 0 -> a clearance-weighted sample of
+    min(top_k, L) views (sample_clearest), else all views from the clearest down."""
+    ids = np.sort(np.array([m.group(1) for m in map(_QM_FILE.match, os.listdir(imset_dir)) if m]))
+    score_file = os.path.join(imset_dir, "clearance.npy")
+    if not os.path.isfile(score_file):
         raise Exception("please call the save_clearance.py before call DataLoader")
-    clearances = np.load(join(imset_dir, "clearance.npy"))
+    scores = np.load(score_file)
     if top_k is not None and top_k > 0:
-        top_k = min(top_k, len(idx_names))
-        i_samples = sample_clearest(clearances, n=top_k, beta=beta, seed=seed)
-        return idx_names[i_samples], clearances[i_samples]
-    order = np.argsort(clearances)[::-1]
-    return idx_names[order], clearances[order]
+        pick = sample_clearest(scores, n=min(top_k, len(ids)), beta=beta, seed=seed)
+    else:
+        pick = np.flip(np.argsort(scores))
+    return ids[pick], scores[pick]
 
 
 def _corner(lr_side, patch_size, seed):
-    """Random patch corner (DataLoader.py:130-136): two randint draws after an optional re-seed."""
+    """Random patch corner (row, column): an optional re-seed, then two `np.random.randint(0, side - patch)` draws, row first."""
     if seed is not None:
         np.random.seed(seed)
-    x = np.random.randint(low=0, high=lr_side - patch_size)
-    y = np.random.randint(low=0, high=lr_side - patch_size)
-    return x, y
+    limit = lr_side - patch_size
+    row = np.random.randint(low=0, high=limit)
+    col = np.random.randint(low=0, high=limit)
+    return row, col
 
 
 def read_imageset(imset_dir, create_patches=False, patch_size=64, seed=None, top_k=None, beta=0.):
-    """ImageSet(name, lr uint16 (L,H,W), hr uint16 or None, hr_map bool, clearances) - the reference's return value, decoded
-    by the native PNG reader."""
-    idx_names, clearances = _select(imset_dir, top_k, beta, seed)
-    lr_images = np.array([io_binding.png_read(join(imset_dir, f"LR{i}.png")) for i in idx_names], dtype=np.uint16)
-    hr_map = io_binding.png_read(join(imset_dir, "SM.png")).astype(bool)
-    hr = io_binding.png_read(join(imset_dir, "HR.png")).astype(np.uint16) if exists(join(imset_dir, "HR.png")) else None
+    """ImageSet(name, lr uint16 (L,H,W), hr uint16 or None, hr_map bool, clearances) of one imageset directory, PNGs decoded by
+    the native reader.  With `create_patches` one random `patch_size` window is cut from every LR view and the matching 3x
+    window from SM / HR."""
+    ids, scores = _views_in_use_order(imset_dir, top_k, beta, seed)
+    asset = lambda name: os.path.join(imset_dir, name)
+    lr = np.stack([io_binding.png_read(asset(f"LR{i}.png")) for i in ids]).astype(np.uint16, copy=False)
+    hr_map = io_binding.png_read(asset("SM.png")) != 0
+    hr = io_binding.png_read(asset("HR.png")).astype(np.uint16, copy=False) if os.path.exists(asset("HR.png")) else None
     if create_patches:
-        x, y = _corner(lr_images[0].shape[0], patch_size, seed)
-        lr_images = get_patch(lr_images, x, y, patch_size)
-        hr_map = get_patch(hr_map, x * 3, y * 3, patch_size * 3)
+        row, col = _corner(lr.shape[1], patch_size, seed)
+        lr = get_patch(lr, row, col, patch_size)
+        hr_map = get_patch(hr_map, 3 * row, 3 * col, 3 * patch_size)
         if hr is not None:
-            hr = get_patch(hr, x * 3, y * 3, patch_size * 3)
-    return ImageSet(name=basename(imset_dir), lr=np.array(lr_images), hr=hr, hr_map=hr_map, clearances=clearances)
+            hr = get_patch(hr, 3 * row, 3 * col, 3 * patch_size)
+    return ImageSet(name=os.path.basename(imset_dir), lr=np.array(lr), hr=hr, hr_map=hr_map, clearances=scores)
 
 
 class ImagesetDataset(Dataset):
-    """Dataset over imageset directories; `__getitem__` returns the reference's ImageSet of float32 tensors."""
+    """Dataset over imageset directories.  `dataset[i]` (int), `dataset["imgsetXXXX"]` (name) -> one ImageSet of float32
+    tensors (lr (L,S,S), hr / hr_map (3S,3S); test imagesets keep hr = None and a bool numpy hr_map); a slice -> a list."""
 
     def __init__(self, imset_dir, config, seed=None, top_k=-1, beta=0.):
         super().__init__()
         self.imset_dir = imset_dir
-        self.name_to_dir = {basename(im_dir): im_dir for im_dir in imset_dir}
-        self.create_patches = config["create_patches"]
-        self.patch_size = config["patch_size"]
-        self.seed = seed
-        self.top_k = top_k
-        self.beta = beta
+        self.name_to_dir = dict(zip(map(os.path.basename, imset_dir), imset_dir))
+        self.create_patches, self.patch_size = config["create_patches"], config["patch_size"]
+        self.seed, self.top_k, self.beta = seed, top_k, beta          # seed: re-seeds numpy's global RNG per imageset when set
 
     def __len__(self):
         return len(self.imset_dir)
 
+    def _resolve(self, index):
+        """Directories an index stands for, and whether the caller gets a bare ImageSet (int / name) or a list (slice)."""
+        if isinstance(index, str):
+            return [self.name_to_dir[index]], True
+        if isinstance(index, slice):
+            picked = self.imset_dir[index]
+            return picked, len(picked) == 1
+        if isinstance(index, int):
+            return [self.imset_dir[operator.index(index)]], True
+        raise KeyError("index must be int, string, or slice")
+
+    def __getitem__(self, index):
+        dirs, single = self._resolve(index)
+        loaded = [self._load_one(d) for d in dirs]
+        return loaded[0] if single else loaded
+
     def _plan(self, dir_):
         """Everything random / directory-dependent for one imageset, in the reference's RNG order."""
-        idx_names, clearances = _select(dir_, self.top_k, self.beta, self.seed)
-        lr_paths = [join(dir_, f"LR{i}.png") for i in idx_names]
+        idx_names, clearances = _views_in_use_order(dir_, self.top_k, self.beta, self.seed)
+        lr_paths = [os.path.join(dir_, f"LR{i}.png") for i in idx_names]
         lr_side = io_binding.png_info(lr_paths[0])[0]
         corner = _corner(lr_side, self.patch_size, self.seed) if self.create_patches else (0, 0)
-        hr_path = join(dir_, "HR.png") if exists(join(dir_, "HR.png")) else None
-        return dict(name=basename(dir_), lr_paths=lr_paths, clearances=clearances, lr_side=lr_side, corner=corner, hr=hr_path,
-                    sm=join(dir_, "SM.png"))
+        hr_path = os.path.join(dir_, "HR.png") if os.path.exists(os.path.join(dir_, "HR.png")) else None
+        return dict(name=os.path.basename(dir_), lr_paths=lr_paths, clearances=clearances, lr_side=lr_side, corner=corner, hr=hr_path,
+                    sm=os.path.join(dir_, "SM.png"))
 
     def _load_one(self, dir_):
         pl = self._plan(dir_)
         patch = self.patch_size if self.create_patches else 0
         out = io_binding.collate([pl["lr_paths"]], [pl["hr"]], [pl["sm"]], min_L=len(pl["lr_paths"]), lr_size=pl["lr_side"], patch=patch,
                                  corners=[pl["corner"]])
-        imset = ImageSet(name=pl["name"], lr=torch.from_numpy(out["lrs"][0]),
-                         hr=torch.from_numpy(out["hrs"][0]) if pl["hr"] is not None else None,
-                         hr_map=torch.from_numpy(out["maps"][0]) if pl["hr"] is not None else out["maps"][0].astype(bool),
-                         clearances=pl["clearances"])
-        return imset
-
-    def __getitem__(self, index):
-        if isinstance(index, int):
-            dirs = [self.imset_dir[index]]
-        elif isinstance(index, str):
-            dirs = [self.name_to_dir[index]]
-        elif isinstance(index, slice):
-            dirs = self.imset_dir[index]
-        else:
-            raise KeyError("index must be int, string, or slice")
-        imsets = [self._load_one(d) for d in dirs]
-        return imsets[0] if len(imsets) == 1 else imsets
+        labelled = pl["hr"] is not None
+        return ImageSet(name=pl["name"], lr=torch.from_numpy(out["lrs"][0]), hr=torch.from_numpy(out["hrs"][0]) if labelled else None,
+                        hr_map=torch.from_numpy(out["maps"][0]) if labelled else out["maps"][0].astype(bool), clearances=pl["clearances"])
 
     def load_batch(self, indices, min_L, pin_memory=False, n_threads=0):
         """One collated batch (padded_lr (B,min_L,S,S), alphas (B,min_L), hrs (B,3S,3S) or [], hr_maps (B,3S,3S), names) decoded
