@@ -41,5 +41,9 @@ int hrn_launch_conv3x3_v4(int cout, const ConvParams& p, hipStream_t stream);
 // bf16 128 -> 128, the v4 structure on v_mfma_f32_16x16x32_bf16 (conv3x3_v5.hip); -100 = not applicable.
 int hrn_launch_conv3x3_v5(const ConvParams& p, hipStream_t stream);
 
+// bf16 128 -> {128, 64}, round 2: descriptor-based halo DMA issued from the MFMA gaps, LDS-staged epilogue (conv3x3_v6.hip);
+// -100 = not applicable.
+int hrn_launch_conv3x3_v6(int cout, const ConvParams& p, hipStream_t stream);
+
 // Pack OIHW f32 weights [cout][cin][3][3] into the kernel's step-major layout (device to device).
 int hrn_launch_conv_pack(int dt, int cin, int cout, const float* w_oihw, void* packed, hipStream_t stream);

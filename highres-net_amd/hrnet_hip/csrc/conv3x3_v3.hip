@@ -514,6 +514,12 @@ int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t st
         if (r64) { const int rc = hrn_launch_conv3x3_r64(p, stream); if (rc != -100) return rc; }
         return offload ? launch_v3<64, 64, true>(p, stream) : launch_v3<64, 64, false>(p, stream);
     }
+    if (cin == 128) {
+        // round 2: conv3x3_v6.hip for the three layers of a fusion level; HRN_CONV_V6=0 falls back to v5 / v4 (A/B timing)
+        static int v6 = -1;
+        if (v6 < 0) { const char* e = getenv("HRN_CONV_V6"); v6 = e ? atoi(e) : 1; }
+        if (v6) { const int rc = hrn_launch_conv3x3_v6(cout, p, stream); if (rc != -100) return rc; }
+    }
     if (cin == 128 && cout == 128) {
         // the same structure on v_mfma_f32_16x16x32_bf16 (conv3x3_v5.hip).  HRN_CONV_V5 = 0: off, 1 (default): layers without a
         // residual, 2: with the pair-gather residual too (ties v4 there)

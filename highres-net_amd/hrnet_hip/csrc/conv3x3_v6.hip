@@ -1,0 +1,510 @@
+// conv3x3 128 -> {128, 64}, bf16, round 2: the three layers of a fusion level (HRNet.py:90-97, :113-131) on
+// v_mfma_f32_16x16x32_bf16.  Same tile, operand images, swizzles and hand-issued fragment reads as conv3x3_v5.hip (512-pixel
+// tiles, 8 MFMA waves, two per SIMD, LDS-DMA staging, one barrier per stage); what changed, and why (stamps of round 1,
+// profiles/r01_final_inkernel_stamps.txt: a halo DMA piece cost its wave ~320 cycles of issue against ~90 for a weight piece,
+// and the epilogue with the residual was 19-24 k of a 77-80 k cycle tile):
+//   * halo DMA through a buffer descriptor (buffer_load_dwordx4 ... lds): the per-lane byte offsets of a wave's <= 5 pieces
+//     are computed ONCE per tile (5 registers); a lane whose halo pixel lies outside the image carries offset 0x80000000,
+//     which the descriptor's range check turns into zeros written to LDS (checked on the hardware: scratch micro-test,
+//     DESIGN.md section 3.1).  No address arithmetic, no bounds tests and no zero page per piece any more; the channel
+//     chunk and the weight stage travel in the scalar offset.  Weights go through a descriptor too (lane offset constant).
+//   * every DMA is issued from an MFMA gap of the stage (one piece after every eighth MFMA), by all eight waves alike, instead
+//     of in a block before (waves 4-7) or after (waves 0-3) the wave's MFMAs.
+//   * the epilogue goes through 4 KB of wave-private LDS: the residual (the pair gather z, or s_i of the view stack) is
+//     fetched with lane-contiguous 16-byte loads (an instruction covers 8 whole 128-byte lines, not 64 lines with 16 bytes
+//     each), written to the staging rows, and read back in the accumulator layout (8 bytes = the 4 channels of one
+//     accumulator quad); the finished bf16 rows take the same way back and leave as whole lines.  No lane exchanges at all.
+//     The staging rows are XOR-swizzled per pixel so that both views of them are bank-conflict-free.
+//   * to make room for the staging area the weight ring has two slots, not three: stage s+1's weights are issued first
+//     thing in stage s and waited for at its end (they are L2 hits, one stage = ~1.5 us).
+// RESM: 0 none | 2 the pair gather z (COUT = 128: t2 = z + PReLU(conv(t1))) | 3 s_i + alpha_partner * f into the view stack
+// (COUT = 64, HRNet.py:123-131).
+// LDS (COUT = 128): 2 x 24,576 (weights) + 2 x 39,936 (halo) + 512 (bias) + 8 x 4,096 (staging) = 162,304 B.
+// Ordering rules (guide, "Pipelining across barriers"): a wave waits for its own DMAs with a counted vmcnt BEFORE the
+// barrier that precedes the stage reading them; a buffer is re-filled only after a barrier every reader of its previous
+// contents has passed.  vmcnt counts in issue order, so a stage issues its weights first and its halo pieces last: waiting
+// until only the halo pieces are outstanding retires the weights and everything older.
+#include <type_traits>
+#include "conv3x3.h"
+
+// Timing-only ablations (tools/v6_abl.sh builds scratch/x/v6_<bits>/lib.so with -DV6_ABL=<bits>; results are WRONG when set):
+// 1 no MFMA | 2 no epilogue | 4 no DMA | 8 no output stores | 16 no residual loads | 32 no fragment reads
+#ifndef V6_ABL
+#define V6_ABL 0
+#endif
+
+namespace {
+
+constexpr int T6_H = 16, T6_W = 32;
+constexpr int HW6 = T6_W + 2;                              // halo width 34
+constexpr int NPIX6 = (T6_H + 2) * HW6;                    // 612 halo pixels
+constexpr int N_IN6 = (NPIX6 * 64 + 1023) / 1024;          // 39 DMA pieces of 1 KB per 32-channel halo chunk
+constexpr int IN_BYTES6 = N_IN6 * 1024;                    // 39,936
+constexpr unsigned OOB6 = 0x80000000u;                     // byte offset no descriptor of this kernel covers
+
+template <int COUT> struct G6 {
+    static constexpr int NCB = COUT / 16;                  // cout blocks of 16 per wave
+    static constexpr int NQ = NCB / 2;                     // steps per tap (2 cout blocks x 4 pixel blocks = 8 MFMAs each)
+    static constexpr int TAP_BYTES = COUT * 64;            // one tap x 32 cin
+    static constexpr int WST = 3 * TAP_BYTES;              // one stage: 24,576 | 12,288
+    static constexpr int W_PIECES = WST / 1024;            // 24 | 12
+    static constexpr int OFF_IN = 2 * WST;
+    static constexpr int OFF_BIAS = OFF_IN + 2 * IN_BYTES6;
+    static constexpr int OFF_STG = OFF_BIAS + 512;
+    static constexpr int ROW = COUT * 2;                   // bytes per output pixel
+    static constexpr int SEGS = ROW / 16;                  // 16-byte segments per pixel: 16 | 8
+    static constexpr int STG_WAVE = 16 * ROW;              // one round = one block of 16 pixels: 4,096 | 2,048
+    static constexpr int NPC = STG_WAVE / 1024;            // 1 KB pieces per round: 4 | 2
+    static constexpr int PPP = 1024 / ROW;                 // pixels per piece: 4 | 8
+    static constexpr int LDS_BYTES = OFF_STG + 8 * STG_WAVE;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr6;
+
+__device__ __forceinline__ float raw_max6(float a, float b) {
+    float y;
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+template <int N> __device__ __forceinline__ void wait_vm6() {
+    static_assert(N >= 0 && N <= 63, "vmcnt");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm6_rt(int n) {       // n is wave-uniform, 0..9
+    switch (n) {
+        case 1: wait_vm6<1>(); break;
+        case 2: wait_vm6<2>(); break;
+        case 3: wait_vm6<3>(); break;
+        case 4: wait_vm6<4>(); break;
+        case 5: wait_vm6<5>(); break;
+        case 6: wait_vm6<6>(); break;
+        case 7: wait_vm6<7>(); break;
+        case 8: wait_vm6<8>(); break;
+        case 9: wait_vm6<9>(); break;
+        default: wait_vm6<0>(); break;
+    }
+}
+__device__ __forceinline__ void barrier6() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ int swz6(int row) { return ((row >> 2) & 1) << 1; }
+
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for6(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for6<N, I + 1>(f); }
+}
+
+template <int COUT, int RESM, bool PAIR>
+__global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) {
+    typedef G6<COUT> GEO;
+    constexpr int NCB = GEO::NCB, NQ = GEO::NQ, NSTEP = 3 * NQ, WST = GEO::WST, TAP_BYTES = GEO::TAP_BYTES;
+    constexpr int OFF_IN = GEO::OFF_IN, ROW = GEO::ROW, SEGS = GEO::SEGS, NPC = GEO::NPC, PPP = GEO::PPP;
+    constexpr bool RES = RESM != 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bias_lds = (float*)(smem + GEO::OFF_BIAS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c15 = lane & 15, q = lane >> 4;
+    const int H = p.H, W = p.W;
+    const unsigned hw = (unsigned)(H * W);
+    const unsigned tiles_x = (W + T6_W - 1) / T6_W;
+    const unsigned tiles_y = (H + T6_H - 1) / T6_H;
+    const unsigned tiles = tiles_x * tiles_y;
+    const unsigned total = tiles * (unsigned)p.M;
+    const unsigned G = gridDim.x;
+    const unsigned bid = blockIdx.x;
+    const unsigned slot0 = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;      // each XCD walks a contiguous run of tiles
+    if (slot0 >= total) return;
+    const int ntl = (int)((total - slot0 + G - 1) / G);
+    unsigned cur_m = slot0 / tiles, cur_t = slot0 - cur_m * tiles;
+    const unsigned step_m = G / tiles, step_t = G - step_m * tiles;
+    constexpr bool in_pair = PAIR;                           // the conv input is the pair gather cat(view i, partner) of the stack
+    constexpr unsigned in_pitch = in_pair ? 128u : 256u;
+    const unsigned char* const src0 = (const unsigned char*)(in_pair ? p.stack : p.in);
+    const unsigned img_bytes = hw * in_pitch;               // < 2^31 (checked by the launcher)
+
+    // ---- where image m of the input lives, as byte offsets from src0: (view A, view B) for the pair gather (chunks 0-1 / 2-3),
+    // else one tensor image.  (Offsets, not pointers: a select between pointers in front of make_buffer_rsrc keeps hipcc from
+    // promoting ANY local of this kernel to registers - ROCm 7.2.)
+    auto in_bases = [&](unsigned m, size_t& a, size_t& b) __attribute__((always_inline)) {
+        if (in_pair) {
+            const unsigned bb = m / (unsigned)p.pair_h, i = m - bb * (unsigned)p.pair_h;
+            a = ((size_t)bb * p.pair_vs + i) * hw * 128;
+            b = ((size_t)bb * p.pair_vs + (p.pair_last - i)) * hw * 128;
+        } else {
+            a = b = (size_t)m * hw * 256;
+        }
+    };
+    // ---- per-lane byte offsets of this wave's halo pieces for tile t (pieces j = w + 8 jj < 39; lane i -> halo pixel
+    // j*16 + (i >> 2), physical 16-byte chunk i & 3 = logical chunk ^ swz6(pixel)); invalid pixels -> OOB6
+    unsigned hoff[5];
+    auto tile_offsets = [&](unsigned t) __attribute__((always_inline)) {
+        const int ty = t / tiles_x;
+        const int y0 = ty * T6_H, x0 = (t - ty * tiles_x) * T6_W;
+        int lq = lane;
+        asm volatile("" : "+v"(lq));                        // keep the per-piece geometry out of long-lived registers
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const int pix = (w + 8 * jj) * 16 + (lq >> 2);
+            const int lc = (lq & 3) ^ swz6(pix);
+            const int py = pix / HW6, px = pix - py * HW6;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool ok = pix < NPIX6 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            hoff[jj] = ok ? (unsigned)(gy * W + gx) * in_pitch + (unsigned)(lc * 16) : OOB6;
+        }
+    };
+    // one halo piece: chunk c (32 channels = 64 bytes of a pixel) of the image behind `rs` -> input buffer `buf`
+    auto dma_halo = [&](__amdgpu_buffer_rsrc_t rs, int c, int buf, int jj) __attribute__((always_inline)) {
+        const int j = w + 8 * jj;
+        if (j < N_IN6) {
+            const unsigned soff = in_pair ? (unsigned)((c & 1) * 64) : (unsigned)(c * 64);
+            if (!(V6_ABL & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr6)(smem + OFF_IN + buf * IN_BYTES6 + j * 1024), 16, hoff[jj], soff, 0, 0);
+        }
+    };
+    // one weight piece of stage (c, tg): piece qq = (tap kx = qq / NCB, cout block jb = qq % NCB): 16 couts x 64 bytes;
+    // lane i -> cout 16 jb + (i >> 2), physical chunk i & 3 = logical (i & 3) ^ swz6(i >> 2)
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 9 * 128 * COUT * 2, 0x00020000);
+    const unsigned w_lane_off = (unsigned)((lane >> 2) * 128 + (((lane & 3) ^ swz6(lane >> 2)) << 4));
+    auto dma_w = [&](int c, int tg, int slot_, int t3) __attribute__((always_inline)) {
+        const int qq = w + 8 * t3;
+        if (qq < GEO::W_PIECES) {
+            const int kx = qq / NCB, jb = qq - kx * NCB;
+            const unsigned soff = (unsigned)(((c >> 1) * 9 + tg * 3 + kx) * (COUT * 128) + (c & 1) * 64 + jb * 2048);
+            if (!(V6_ABL & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr6)(smem + slot_ * WST + kx * TAP_BYTES + jb * 1024), 16, w_lane_off, soff, 0, 0);
+        }
+    };
+    constexpr int NW3 = (GEO::W_PIECES + 7) / 8;            // weight pieces a wave issues per stage: up to 3 | 2
+    const int n_in = w < (N_IN6 & 7) ? (N_IN6 >> 3) + 1 : (N_IN6 >> 3);      // halo pieces of this wave per chunk: 5 (wave 7: 4)
+
+    const bool has_slope = p.slope != nullptr;
+    const float slope = has_slope ? p.slope[0] : 0.f;
+    const bool slope01 = slope >= 0.f && slope <= 1.f;
+
+    // fragment addresses (as conv3x3_v5.hip).  A, cout block cb: a_off + slot*WST + kx*TAP + cb*1024.  B, pixel block pxb = (row
+    // pxb >> 1, column half pxb & 1): halo pixel pixb[pxb] + tg*34 + kx.
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned a_off = lds0 + (unsigned)(c15 * 64 + ((q ^ swz6(c15)) << 4));
+    int pixb[4];
+#pragma unroll
+    for (int pxb = 0; pxb < 4; ++pxb) pixb[pxb] = (2 * w + (pxb >> 1)) * HW6 + 16 * (pxb & 1) + c15;
+    const unsigned q16 = (unsigned)(q << 4);
+
+    f32x4 acc[NCB][4];                                      // [cout block of 16][pixel block of 16]
+
+    // ---- prologue: weights of stage 0, halo chunk 0 of the first tile
+    if (tid < COUT) bias_lds[tid] = p.bias[tid];
+    size_t inA, inB;
+    in_bases(cur_m, inA, inB);
+    tile_offsets(cur_t);
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src0 + inA), 0, (int)img_bytes, 0x00020000);
+#pragma unroll
+        for (int t3 = 0; t3 < NW3; ++t3) dma_w(0, 0, 0, t3);
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) dma_halo(rs, 0, 0, jj);
+    }
+    wait_vm6<0>();
+    barrier6();
+
+    for (int tl = 0; tl < ntl; ++tl) {
+        const bool more_tiles = tl + 1 < ntl;
+        unsigned nxt_t = cur_t + step_t, nxt_m = cur_m + step_m;
+        if (nxt_t >= tiles) { nxt_t -= tiles; ++nxt_m; }
+        size_t nxA = inA, nxB = inB;
+        if (more_tiles) in_bases(nxt_m, nxA, nxB);
+        // accumulators start at the bias: element e of block cb = channel cb*16 + 4q + e
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const f32x4 b = *(const f32x4*)(bias_lds + cb * 16 + 4 * q);
+#pragma unroll
+            for (int pxb = 0; pxb < 4; ++pxb) acc[cb][pxb] = b;
+        }
+        // geometry of this tile's outputs (used by the residual prefetch and the epilogue)
+        const int ty_ = cur_t / tiles_x;
+        const int y0 = ty_ * T6_H, x0 = (cur_t - ty_ * tiles_x) * T6_W;
+        const unsigned char *resA = nullptr, *resB = nullptr;
+        unsigned char* outp;
+        float res_alpha = 1.f;
+        {
+            size_t oimg = cur_m;
+            if (p.out_h > 0) {
+                const unsigned ob = cur_m / (unsigned)p.out_h, oi = cur_m - ob * (unsigned)p.out_h;
+                oimg = (size_t)ob * p.out_vs + oi;
+                if (RESM == 3) {
+                    resA = resB = (const unsigned char*)p.res + ((size_t)ob * p.res_vs + oi) * hw * 128;
+                    if (p.alphas) res_alpha = p.alphas[(size_t)ob * p.alpha_vs + (p.pair_last - oi)];
+                }
+            }
+            if (RESM == 2) {
+                const unsigned bb = cur_m / (unsigned)p.pair_h, i = cur_m - bb * (unsigned)p.pair_h;
+                resA = (const unsigned char*)p.stack + ((size_t)bb * p.pair_vs + i) * hw * 128;
+                resB = (const unsigned char*)p.stack + ((size_t)bb * p.pair_vs + (p.pair_last - i)) * hw * 128;
+            }
+            outp = (unsigned char*)p.out + oimg * hw * ROW;
+        }
+        // residual of round r (= pixel block r of the wave): piece k, lane i <-> pixel pp = PPP*k + i / SEGS of the block and the
+        // 16-byte segment s = i % SEGS of its row.  Round 0 goes straight into the wave's staging rows by LDS-DMA during the tile's
+        // last stage (no registers to hold it beside the fragments): the DMA writes lane i's 16 bytes to position i, which in the
+        // swizzled row is logical segment s ^ key(pp), so that is the segment the lane fetches.  Rounds 1-3 are fetched into the
+        // (then dead) fragment registers when the epilogue starts, by inline asm: hipcc would sink plain loads to their uses
+        // (one exposed HBM round trip per round) and answer the first use with vmcnt(0).
+        auto res_src = [&](int r, int k, bool swizzled) __attribute__((always_inline)) -> const unsigned char* {
+            const int gy = y0 + 2 * w + (r >> 1), gyc = gy < H ? gy : H - 1;
+            int lq = lane;
+            asm volatile("" : "+v"(lq));
+            const int pp = PPP * k + lq / SEGS;
+            const int kk = SEGS == 16 ? pp : ((pp & 7) ^ (pp >> 3));
+            const int s = swizzled ? (lq % SEGS) ^ kk : lq % SEGS;
+            const int gx = x0 + 16 * (r & 1) + pp, gxc = gx < W ? gx : W - 1;
+            const unsigned char* view = (RESM == 2 && s >= 8) ? resB : resA;
+            return view + (unsigned)((gyc * W + gxc) * 128 + (s & 7) * 16);
+        };
+        auto res_dma0 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NPC; ++k)
+                if (!(V6_ABL & 16))
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)res_src(0, k, true),
+                                                     (lds_ptr6)(smem + GEO::OFF_STG + w * GEO::STG_WAVE + k * 1024), 16, 0, 0);
+        };
+
+        for (int c = 0; c < 4; ++c) {
+            const unsigned inbase = (unsigned)(OFF_IN + (c & 1) * IN_BYTES6);
+            if (c == 3) {        // this tile's last halo chunk is on its way: from here on the DMA state describes the next tile
+                inA = nxA; inB = nxB;
+                if (more_tiles) tile_offsets(nxt_t);
+            }
+            auto stage = [&](auto tg_c) __attribute__((always_inline)) {
+                constexpr int tg = decltype(tg_c)::value;
+                const int slot_r = (c + tg) & 1;                                        // ring slot this stage reads
+                const bool have_next = c < 3 || tg < 2 || more_tiles;                   // there is a stage s+1
+                const bool next_chunk = c < 3 || more_tiles;                            // there is a halo chunk after this one
+                const int tg2 = (tg + 1) % 3, c2 = (c + (tg + 1) / 3) & 3;
+                // the image the next halo chunk comes from
+                const int cn = (c + 1) & 3;
+                const size_t hb = (in_pair && cn >= 2) ? inB : inA;      // at c == 3 these already are the next tile's views
+                const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(src0 + hb), 0, (int)img_bytes, 0x00020000);
+                // DMA item `it` of this stage, issued from the gap behind the it-th step: weights of stage s+1 first, then (tg 0: pieces
+                // jj 0-2, tg 1: pieces 3-4) of the next halo chunk
+                auto issue_item = [&](int it) __attribute__((always_inline)) {
+                    if (it < NW3) { if (have_next) dma_w(c2, tg2, slot_r ^ 1, it); }
+                    else if (tg == 0 && it < NW3 + 3) { if (next_chunk) dma_halo(rs_h, cn, cn & 1, it - NW3); }
+                    else if (tg == 1 && it < NW3 + 2) { if (next_chunk) dma_halo(rs_h, cn, cn & 1, it - NW3 + 3); }
+                };
+                constexpr int N_ITEMS = NW3 + (tg == 0 ? 3 : tg == 1 ? 2 : 0);
+                static_assert(N_ITEMS <= NSTEP, "one DMA item per step");
+                int halo_out = 0;                                                      // halo pieces this wave leaves in flight
+                if (next_chunk) halo_out = tg == 0 ? 3 : tg == 1 ? n_in - 3 : 0;
+                if (RES && tg == 2 && c == 3 && !(V6_ABL & (2 | 128))) res_dma0();
+                // ---- NSTEP steps = 3 taps x NQ cout pairs, 8 MFMAs each; hand-issued fragment reads with counted waits
+                // (conv3x3_v5.hip explains the counts)
+                const unsigned abase = a_off + (unsigned)(slot_r * WST);
+                bf16x8 fa[2][2], fb[2][4];
+                auto rd = [&](bf16x8& dst, unsigned addr, int imm) __attribute__((always_inline)) {
+                    if (V6_ABL & 32) asm volatile("; no read" : "=v"(dst) : "v"(addr), "n"(imm));
+                    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
+                };
+                auto load_b1 = [&](int tap, int pxb) __attribute__((always_inline)) {
+                    int pb0 = pixb[pxb];
+                    asm volatile("" : "+v"(pb0));
+                    const int pix = pb0 + tg * HW6 + tap;
+                    rd(fb[tap & 1][pxb], lds0 + inbase + (unsigned)(pix << 6) + (q16 ^ (unsigned)((pix & 4) << 3)), 0);
+                };
+                auto load_a1 = [&](int i, int k) __attribute__((always_inline)) {       // step i = (tap i / NQ, cout pair i % NQ)
+                    rd(fa[i & 1][k], abase, (i / NQ) * TAP_BYTES + (i % NQ) * 2048 + k * 1024);
+                };
+#pragma unroll
+                for (int pxb = 0; pxb < 4; ++pxb) load_b1(0, pxb);
+                load_a1(0, 0);
+                load_a1(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for6<NSTEP>([&](auto i_c) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_c)::value;          // a true constant: the DMA item behind step i indexes hoff[]
+                    constexpr int qt = i % NQ, tap = i / NQ, bs = tap & 1;
+                    constexpr bool a_next = i + 1 < NSTEP;
+                    // the step that issues the next tap's B reads: the second step of a tap (NQ >= 2), with one more tap to go
+                    constexpr bool b_cur = qt == (NQ > 1 ? 1 : 0) && tap + 1 < 3;
+                    constexpr bool b_prev = i >= 1 && ((i - 1) % NQ) == (NQ > 1 ? 1 : 0) && (i - 1) / NQ + 1 < 3;
+                    // reads allowed to be outstanding at the two waits of a step: before MFMA 0 (needs A0(i); with NQ == 2 the B
+                    // fragments issued in the previous step are needed at once: everything) and before MFMA 4 (needs A1(i))
+                    constexpr int n0 = (b_prev && NQ == 2) ? 0 : 1 + (b_prev ? 4 : 0);
+                    constexpr int n4 = (b_prev ? 4 : 0) + (a_next ? 2 : 0) + (b_cur ? 2 : 0);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int k = g >> 2, pxb = g & 3;
+                        if (g == 0) {
+                            if (n0 == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[i & 1][0]), "+v"(fb[bs][0]), "+v"(fb[bs][1]), "+v"(fb[bs][2]), "+v"(fb[bs][3]));
+                            else if (n0 == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[i & 1][0]), "+v"(fb[bs][0]));
+                            else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[i & 1][0]), "+v"(fb[bs][0]));
+                        } else if (g == 4) {
+                            if (n4 == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[i & 1][1]));
+                            else if (n4 == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[i & 1][1]));
+                            else if (n4 == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[i & 1][1]));
+                            else if (n4 == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[i & 1][1]));
+                            else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[i & 1][1]));
+                        } else if (k == 0) asm volatile("" : "+v"(fb[bs][pxb]));
+                        if (V6_ABL & 1) asm volatile("" : "+v"(acc[qt * 2 + k][pxb]) : "v"(fa[i & 1][k]), "v"(fb[bs][pxb]));
+                        else acc[qt * 2 + k][pxb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][k], fb[bs][pxb], acc[qt * 2 + k][pxb], 0, 0, 0);
+                        if (g < 2 && a_next) load_a1(i + 1, g);
+                        if (g >= 2 && g < 6 && b_cur) load_b1(tap + 1, g - 2);
+                        if (g == 7 && i < N_ITEMS) issue_item(i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                // stage s+1's weights (and every older DMA) have landed once only this stage's halo pieces are outstanding
+                wait_vm6_rt(halo_out);                                   // tg 2: 0 (the residual prefetch is older than the weights)
+                if (tg == 2 && c == 3 && (V6_ABL & 2)) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int pxb = 0; pxb < 4; ++pxb) asm volatile("" :: "v"(acc[cb][pxb]));
+                }
+                if (tg == 2 && c == 3 && !(V6_ABL & 2)) {
+                    // ---- epilogue of this tile: registers, global memory and this wave's staging rows only
+                    unsigned char* stg = smem + GEO::OFF_STG + w * GEO::STG_WAVE;
+                    u32x4 rq[4][NPC];
+                    if (RES) {
+#pragma unroll
+                        for (int r = (V6_ABL & 128) ? 0 : 1; r < 4; ++r)
+#pragma unroll
+                            for (int k = 0; k < NPC; ++k) {
+                                const unsigned char* src = res_src(r, k, false);
+                                if (V6_ABL & 16) rq[r][k] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+                                else rq[r][k] = *(const u32x4*)src;
+                            }
+                    }
+                    int le = lane;
+                    asm volatile("" : "+v"(le));                    // every lane-derived address below is formed here, per tile
+                    const int c15e = le & 15, qe = le >> 4;
+                    // a pixel's staging row holds its ROW bytes with the 16-byte segments XOR-ed by a per-pixel key
+                    const int key = SEGS == 16 ? c15e : ((c15e & 7) ^ (c15e >> 3));
+                    auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
+                        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int gy = y0 + 2 * w + (r >> 1);
+                            if (RES && (r > 0 || (V6_ABL & 128))) {
+                                // plain loads, waited for by hipcc (inline-asm loads were tried: hipcc copies their destination registers
+                                // in front of the hand-placed wait, i.e. before the data has landed)
+#pragma unroll
+                                for (int k = 0; k < NPC; ++k) {
+                                    const int pp = PPP * k + le / SEGS, s = le % SEGS;
+                                    const int kk = SEGS == 16 ? pp : ((pp & 7) ^ (pp >> 3));
+                                    *(u32x4*)(stg + pp * ROW + ((s ^ kk) << 4)) = rq[r][k];
+                                }
+                            }
+                            // batched: all residual cells first, then the arithmetic, then all result cells, then the row pieces (with an
+                            // LDS-DMA in the kernel hipcc answers every LDS read's first use with lgkmcnt(0): one round trip per batch)
+                            unsigned cell[NCB];
+#pragma unroll
+                            for (int cb = 0; cb < NCB; ++cb) cell[cb] = (unsigned)(c15e * ROW + (((2 * cb + (qe >> 1)) ^ key) << 4) + (qe & 1) * 8);
+                            u32x2 rr[NCB];
+                            if (RES) {
+#pragma unroll
+                                for (int cb = 0; cb < NCB; ++cb) rr[cb] = *(const u32x2*)(stg + cell[cb]);
+                            }
+                            u32x2 o[NCB];
+#pragma unroll
+                            for (int cb = 0; cb < NCB; ++cb) {
+                                float x[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) x[e] = acc[cb][r][e];
+                                if (ACT == 1) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) x[e] = raw_max6(x[e], slope * x[e]);
+                                } else if (ACT == 2) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) x[e] = x[e] >= 0.f ? x[e] : slope * x[e];
+                                }
+                                if (RES) {
+                                    const float r0 = __uint_as_float(rr[cb][0] << 16), r1 = __uint_as_float(rr[cb][0] & 0xffff0000u);
+                                    const float r2 = __uint_as_float(rr[cb][1] << 16), r3 = __uint_as_float(rr[cb][1] & 0xffff0000u);
+                                    if (RESM == 3) { x[0] = r0 + res_alpha * x[0]; x[1] = r1 + res_alpha * x[1]; x[2] = r2 + res_alpha * x[2]; x[3] = r3 + res_alpha * x[3]; }
+                                    else { x[0] += r0; x[1] += r1; x[2] += r2; x[3] += r3; }
+                                }
+                                o[cb][0] = pack2_bf16(x[0], x[1]);
+                                o[cb][1] = pack2_bf16(x[2], x[3]);
+                            }
+#pragma unroll
+                            for (int cb = 0; cb < NCB; ++cb) *(u32x2*)(stg + cell[cb]) = o[cb];
+                            u32x4 vv[NPC];
+#pragma unroll
+                            for (int k = 0; k < NPC; ++k) {
+                                const int pp = PPP * k + le / SEGS, s = le % SEGS;
+                                const int kk = SEGS == 16 ? pp : ((pp & 7) ^ (pp >> 3));
+                                vv[k] = *(const u32x4*)(stg + pp * ROW + ((s ^ kk) << 4));
+                            }
+#pragma unroll
+                            for (int k = 0; k < NPC; ++k) {
+                                const int pp = PPP * k + le / SEGS, s = le % SEGS;
+                                const int gx = x0 + 16 * (r & 1) + pp;
+                                if (V6_ABL & 8) asm volatile("" :: "v"(vv[k]));
+                                else if (gy < H && gx < W) *(u32x4*)(outp + (unsigned)((gy * W + gx) * ROW + s * 16)) = vv[k];
+                            }
+                        }
+                    };
+                    if (!has_slope) epilogue(std::integral_constant<int, 0>{});
+                    else if (slope01) epilogue(std::integral_constant<int, 1>{});
+                    else epilogue(std::integral_constant<int, 2>{});
+                }
+                barrier6();
+            };
+            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 2>{});
+        }
+        cur_m = nxt_m; cur_t = nxt_t;
+    }
+    wait_vm6<0>();                                          // nothing of this workgroup may still be in flight when it ends
+}
+
+int g_v6_cus[16];
+
+template <int COUT, int RESM, bool PAIR>
+int launch_v6(const ConvParams& p, long grid, hipStream_t stream) {
+    typedef G6<COUT> GEO;
+    static_assert(GEO::LDS_BYTES <= 160 * 1024, "LDS budget");
+    { const int rc_lds = hrn_allow_lds((const void*)conv3x3_v6_kernel<COUT, RESM, PAIR>, GEO::LDS_BYTES); if (rc_lds) return rc_lds; }
+    hipLaunchKernelGGL((conv3x3_v6_kernel<COUT, RESM, PAIR>), dim3((unsigned)grid), dim3(512), GEO::LDS_BYTES, stream, p);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// bf16, 128 input channels.  COUT = 128: residual none or the pair gather (res_mode 2); COUT = 64: none or the alpha residual into
+// the view stack (res_mode 3).  Returns -100 when not applicable.
+int hrn_launch_conv3x3_v6(int cout, const ConvParams& p, hipStream_t stream) {
+    if (p.scale || p.relu) return -100;
+    if (cout != 64 && cout != 128) return -100;
+    if (cout == 128 && p.res_mode != 0 && p.res_mode != 2) return -100;
+    if (cout == 64 && ((p.res_mode != 0 && p.res_mode != 3) || p.in_pair)) return -100;
+    if ((p.in_pair || p.res_mode == 2) && p.pair_h <= 0) return -100;
+    if (p.res_mode == 3 && (p.out_h <= 0 || !p.res)) return -100;
+    int dev = 0;
+    HRN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return -100;
+    if (g_v6_cus[dev] == 0) {
+        int n = 0;
+        HRN_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        g_v6_cus[dev] = n > 0 ? n : 256;
+    }
+    const long tiles = (long)((p.W + T6_W - 1) / T6_W) * ((p.H + T6_H - 1) / T6_H);
+    const long total = tiles * p.M;
+    HRN_CHECK(total > 0, -2, "conv3x3_v6: bad tile count %ld", total);
+    if (total >= (1L << 30) || (long)p.H * p.W * 256 >= (1L << 31)) return -100;     // 32-bit tile / in-image byte arithmetic
+    long grid = g_v6_cus[dev];
+    if (total < grid) grid = total;
+    if (grid >= 8) grid &= ~7L;
+    const double px = (double)p.M * p.H * p.W;
+    const char* fam = cout == 128 ? (p.res_mode ? "conv3x3_bf16_128x128+res" : "conv3x3_bf16_128x128")
+                                  : (p.res_mode ? "conv3x3_bf16_128x64+res" : "conv3x3_bf16_128x64");
+    HrnProfScope prof(fam, 2.0 * 128 * cout * 9 * px, px * 2 * (128 + cout + (p.res_mode ? cout : 0)), stream);
+    if (cout == 128) {
+        if (p.in_pair) return p.res_mode ? launch_v6<128, 2, true>(p, grid, stream) : launch_v6<128, 0, true>(p, grid, stream);
+        return p.res_mode ? launch_v6<128, 2, false>(p, grid, stream) : launch_v6<128, 0, false>(p, grid, stream);
+    }
+    return p.res_mode ? launch_v6<64, 3, false>(p, grid, stream) : launch_v6<64, 0, false>(p, grid, stream);
+}
