@@ -32,6 +32,16 @@
 #ifndef V6_ABL
 #define V6_ABL 0
 #endif
+#ifndef V6_BAL
+#define V6_BAL 4          // eighths of a stage's steps during which waves 4-7 run at raised priority (0 = off)
+#endif
+
+#ifdef V6_STAMP      // diagnostic build only (tools/stamps/read_v6.py): s_memtime stamps of tile 1 of the largest launch
+__device__ unsigned long long hrn_v6_stamps[256 * 8 * 24];
+#define V6_ST(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (stamp_on) st[i] = t_; } while (0)
+#else
+#define V6_ST(i) do {} while (0)
+#endif
 
 namespace {
 
@@ -187,12 +197,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
     // pxb >> 1, column half pxb & 1): halo pixel pixb[pxb] + tg*34 + kx.
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned a_off = lds0 + (unsigned)(c15 * 64 + ((q ^ swz6(c15)) << 4));
-    int pixb[4];
+    // B fragment addresses, one register per (halo row 2w + j, tap column kx): pixel block pxb of stage tg reads row j = (pxb >> 1)
+    // + tg; its second half (pxb & 1) lies 16 pixels = 1,024 bytes further on (same swizzle: 16 is a multiple of 8).  The input
+    // buffer's offset is folded in once per chunk (bsel), so a read costs no VALU at all (it was 5 per read: stamps).
+    unsigned baddr[4][3];
 #pragma unroll
-    for (int pxb = 0; pxb < 4; ++pxb) pixb[pxb] = (2 * w + (pxb >> 1)) * HW6 + 16 * (pxb & 1) + c15;
-    const unsigned q16 = (unsigned)(q << 4);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pix = (2 * w + j) * HW6 + c15 + kx;
+            baddr[j][kx] = lds0 + (unsigned)OFF_IN + (unsigned)(pix << 6) + ((unsigned)(q << 4) ^ (unsigned)((pix & 4) << 3));
+        }
 
     f32x4 acc[NCB][4];                                      // [cout block of 16][pixel block of 16]
+#ifdef V6_STAMP
+    unsigned long long st[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) st[i] = 0;
+    bool stamp_on = false;
+#endif
 
     // ---- prologue: weights of stage 0, halo chunk 0 of the first tile
     if (tid < COUT) bias_lds[tid] = p.bias[tid];
@@ -211,6 +234,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
 
     for (int tl = 0; tl < ntl; ++tl) {
         const bool more_tiles = tl + 1 < ntl;
+#ifdef V6_STAMP
+        stamp_on = false;
+        if (RESM == 2 && !PAIR && ntl >= 32 && tl == 1) { stamp_on = true; V6_ST(20); }
+        if (RESM == 2 && !PAIR && ntl >= 32 && tl == 2) { stamp_on = true; V6_ST(21); stamp_on = false; }
+#endif
         unsigned nxt_t = cur_t + step_t, nxt_m = cur_m + step_m;
         if (nxt_t >= tiles) { nxt_t -= tiles; ++nxt_m; }
         size_t nxA = inA, nxB = inB;
@@ -271,13 +299,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
         };
 
         for (int c = 0; c < 4; ++c) {
-            const unsigned inbase = (unsigned)(OFF_IN + (c & 1) * IN_BYTES6);
+            if (c > 0 || tl > 0) {      // chunk c sits in input buffer c & 1: move the B addresses over from the other buffer
+                const unsigned d = (c & 1) ? (unsigned)IN_BYTES6 : (unsigned)-IN_BYTES6;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) baddr[j][kx] += d;
+            }
             if (c == 3) {        // this tile's last halo chunk is on its way: from here on the DMA state describes the next tile
                 inA = nxA; inB = nxB;
                 if (more_tiles) tile_offsets(nxt_t);
             }
             auto stage = [&](auto tg_c) __attribute__((always_inline)) {
                 constexpr int tg = decltype(tg_c)::value;
+#ifdef V6_STAMP
+                const bool so_ = stamp_on;
+                stamp_on = so_ && (c == 1 || (c == 3 && tg == 2));
+                const int sb_ = c == 1 ? 4 * tg : 12;
+                V6_ST(sb_ + 0);
+#endif
                 const int slot_r = (c + tg) & 1;                                        // ring slot this stage reads
                 const bool have_next = c < 3 || tg < 2 || more_tiles;                   // there is a stage s+1
                 const bool next_chunk = c < 3 || more_tiles;                            // there is a halo chunk after this one
@@ -307,14 +347,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                     else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
                 };
                 auto load_b1 = [&](int tap, int pxb) __attribute__((always_inline)) {
-                    int pb0 = pixb[pxb];
-                    asm volatile("" : "+v"(pb0));
-                    const int pix = pb0 + tg * HW6 + tap;
-                    rd(fb[tap & 1][pxb], lds0 + inbase + (unsigned)(pix << 6) + (q16 ^ (unsigned)((pix & 4) << 3)), 0);
+                    rd(fb[tap & 1][pxb], baddr[(pxb >> 1) + tg][tap], (pxb & 1) * 1024);
                 };
                 auto load_a1 = [&](int i, int k) __attribute__((always_inline)) {       // step i = (tap i / NQ, cout pair i % NQ)
                     rd(fa[i & 1][k], abase, (i / NQ) * TAP_BYTES + (i % NQ) * 2048 + k * 1024);
                 };
+#if V6_BAL
+                // the SIMD's arbiter prefers the older wave (w) to its partner (w + 4) all stage long: w finishes its 96 MFMAs in ~2.7 k
+                // cycles and then idles at the barrier while w + 4 runs alone at ~60 % of the pipe.  Priority for w + 4 during the first
+                // steps of the stage evens them out (stamps: profiles/r02_v6_stamps.txt)
+                if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int pxb = 0; pxb < 4; ++pxb) load_b1(0, pxb);
                 load_a1(0, 0);
@@ -350,11 +393,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                         if (g < 2 && a_next) load_a1(i + 1, g);
                         if (g >= 2 && g < 6 && b_cur) load_b1(tap + 1, g - 2);
                         if (g == 7 && i < N_ITEMS) issue_item(i);
+#if V6_BAL
+                        if (g == 7 && i == (NSTEP * V6_BAL) / 8 - 1 && w >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
                 // stage s+1's weights (and every older DMA) have landed once only this stage's halo pieces are outstanding
-                wait_vm6_rt(halo_out);                                   // tg 2: 0 (the residual prefetch is older than the weights)
+                V6_ST(sb_ + 1);
+                wait_vm6_rt(halo_out);
+                V6_ST(sb_ + 2);                                   // tg 2: 0 (the residual prefetch is older than the weights)
                 if (tg == 2 && c == 3 && (V6_ABL & 2)) {
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb)
@@ -364,16 +412,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                 if (tg == 2 && c == 3 && !(V6_ABL & 2)) {
                     // ---- epilogue of this tile: registers, global memory and this wave's staging rows only
                     unsigned char* stg = smem + GEO::OFF_STG + w * GEO::STG_WAVE;
+                    // round 1 now, round r + 2 when round r has retired its accumulators: more at once do not fit beside the 128
+                    // accumulators (hipcc then spills freshly loaded pieces, i.e. waits for them on the spot)
                     u32x4 rq[4][NPC];
+                    auto res_load = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int k = 0; k < NPC; ++k) {
+                            const unsigned char* src = res_src(r, k, false);
+                            if (V6_ABL & 16) rq[r][k] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+                            else rq[r][k] = *(const u32x4*)src;
+                        }
+                    };
                     if (RES) {
-#pragma unroll
-                        for (int r = (V6_ABL & 128) ? 0 : 1; r < 4; ++r)
-#pragma unroll
-                            for (int k = 0; k < NPC; ++k) {
-                                const unsigned char* src = res_src(r, k, false);
-                                if (V6_ABL & 16) rq[r][k] = u32x4{(unsigned)lane, 1u, 2u, 3u};
-                                else rq[r][k] = *(const u32x4*)src;
-                            }
+                        if (V6_ABL & 128) res_load(0);
+                        res_load(1);
                     }
                     int le = lane;
                     asm volatile("" : "+v"(le));                    // every lane-derived address below is formed here, per tile
@@ -443,13 +495,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                                 if (V6_ABL & 8) asm volatile("" :: "v"(vv[k]));
                                 else if (gy < H && gx < W) *(u32x4*)(outp + (unsigned)((gy * W + gx) * ROW + s * 16)) = vv[k];
                             }
+                            if (RES && r < 2) res_load(r + 2);           // one round of work between a fetch and its use
                         }
                     };
                     if (!has_slope) epilogue(std::integral_constant<int, 0>{});
                     else if (slope01) epilogue(std::integral_constant<int, 1>{});
                     else epilogue(std::integral_constant<int, 2>{});
                 }
+#ifdef V6_STAMP
+                if (c == 3 && tg == 2) V6_ST(16);
+#endif
                 barrier6();
+                V6_ST(sb_ + 3);
+#ifdef V6_STAMP
+                stamp_on = so_;
+#endif
             };
             stage(std::integral_constant<int, 0>{});
             stage(std::integral_constant<int, 1>{});
@@ -458,6 +518,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
         cur_m = nxt_m; cur_t = nxt_t;
     }
     wait_vm6<0>();                                          // nothing of this workgroup may still be in flight when it ends
+#ifdef V6_STAMP
+    if (RESM == 2 && !PAIR && ntl >= 32 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) hrn_v6_stamps[(bid * 8 + w) * 24 + i] = st[i];
+    }
+#endif
 }
 
 int g_v6_cus[16];
@@ -473,6 +539,12 @@ int launch_v6(const ConvParams& p, long grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef V6_STAMP
+extern "C" int hrn_dbg_read_stamps_v6(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(hrn_v6_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // bf16, 128 input channels.  COUT = 128: residual none or the pair gather (res_mode 2); COUT = 64: none or the alpha residual into
 // the view stack (res_mode 3).  Returns -100 when not applicable.
