@@ -45,5 +45,8 @@ int hrn_launch_conv3x3_v5(const ConvParams& p, hipStream_t stream);
 // -100 = not applicable.
 int hrn_launch_conv3x3_v6(int cout, const ConvParams& p, hipStream_t stream);
 
+// bf16 128 -> {128, 64}: the conv3x3_v6 skeleton on v_mfma_f32_32x32x16_bf16 (conv3x3_v7.hip); -100 = not applicable.
+int hrn_launch_conv3x3_v7(int cout, const ConvParams& p, hipStream_t stream);
+
 // Pack OIHW f32 weights [cout][cin][3][3] into the kernel's step-major layout (device to device).
 int hrn_launch_conv_pack(int dt, int cin, int cout, const float* w_oihw, void* packed, hipStream_t stream);
