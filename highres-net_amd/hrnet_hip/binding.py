@@ -82,6 +82,11 @@ SIGNATURES = {
     "hrn_lanczos_shift_backward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                               _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_get_loss": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "hrn_get_loss_train_workspace_bytes": (_c.c_size_t, [_c.c_int]),
+    "hrn_get_loss_train": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                      _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_get_loss_backward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                         _c.c_int, _c.c_void_p, _c.c_void_p]),
     "hrn_shift_cpsnr_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "hrn_shift_cpsnr": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -504,6 +509,36 @@ def get_loss(srs, hrs, hr_maps, metric="cMSE", crop=0):
     with torch.cuda.device(srs.device):
         _check(lib.hrn_get_loss(_ptr(srs), _ptr(hrs), _ptr(hr_maps), B, S, int(crop), _METRICS[metric], _ptr(out), _stream()), "hrn_get_loss")
     return out
+
+
+def get_loss_train(srs, hrs, hr_maps, metric="cPSNR", crop=0):
+    """Forward of the differentiable loss tail: -> (out (B,), stats (B,4) f64 = {n, bias, cMSE, 0})."""
+    lib = load_library()
+    if metric not in ("cMSE", "cPSNR"):
+        raise ValueError(f"the registered loss is defined for 'cMSE' and 'cPSNR'; got {metric!r}")
+    srs, hrs, hr_maps = _dev_f32(srs, "srs"), _dev_f32(hrs, "hrs"), _dev_f32(hr_maps, "hr_maps")
+    if srs.dim() != 3 or srs.shape != hrs.shape or srs.shape != hr_maps.shape or srs.shape[1] != srs.shape[2]:
+        raise ValueError(f"srs, hrs, hr_maps must be equal (B,S,S) tensors; got {tuple(srs.shape)}, {tuple(hrs.shape)}, {tuple(hr_maps.shape)}")
+    B, S, _ = srs.shape
+    out = torch.empty((B,), dtype=torch.float32, device=srs.device)
+    stats = torch.empty((B, 4), dtype=torch.float64, device=srs.device)
+    with torch.cuda.device(srs.device):
+        ws = _workspace(lib.hrn_get_loss_train_workspace_bytes(B), srs.device, "loss_train")
+        _check(lib.hrn_get_loss_train(_ptr(srs), _ptr(hrs), _ptr(hr_maps), B, S, int(crop), _METRICS[metric], _ptr(out), _ptr(stats),
+                                      _ptr(ws), ws.numel(), _stream()), "hrn_get_loss_train")
+    return out, stats
+
+
+def get_loss_backward(srs, hrs, hr_maps, stats, d_out, metric="cPSNR", crop=0):
+    """d_out (B,) -> d_srs (B,S,S): the brightness bias is a constant, as in the reference (train.py:83)."""
+    lib = load_library()
+    srs, hrs, hr_maps, d_out = _dev_f32(srs, "srs"), _dev_f32(hrs, "hrs"), _dev_f32(hr_maps, "hr_maps"), _dev_f32(d_out, "d_out")
+    B, S, _ = srs.shape
+    d_srs = torch.empty_like(srs)
+    with torch.cuda.device(srs.device):
+        _check(lib.hrn_get_loss_backward(_ptr(srs), _ptr(hrs), _ptr(hr_maps), _ptr(stats), _ptr(d_out), B, S, int(crop),
+                                         _METRICS[metric], _ptr(d_srs), _stream()), "hrn_get_loss_backward")
+    return d_srs
 
 
 def shift_cpsnr(srs, hrs, hr_maps, border_w=3, clip=True):

@@ -364,6 +364,25 @@ int hrn_get_loss(const float* srs, const float* hrs, const float* maps, int B, i
     return hrn_launch_masked_cmse(srs, hrs, maps, B, S, crop, metric, out, (hipStream_t)stream);
 }
 
+size_t hrn_get_loss_train_workspace_bytes(int B) { return B > 0 ? hrn_loss_train_workspace_bytes_impl(B) : 0; }
+
+int hrn_get_loss_train(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out,
+                       double* stats, void* ws, size_t ws_bytes, void* stream) {
+    HRN_CHECK(B > 0 && B <= 65535 && S > 0 && crop >= 0 && 2 * crop < S, -2, "hrn_get_loss_train: bad shape B=%d S=%d crop=%d", B, S, crop);
+    HRN_CHECK(metric == 1 || metric == 2, -2, "hrn_get_loss_train: metric must be 1 (cMSE) or 2 (cPSNR); masked_MSE has no registered form");
+    HRN_CHECK(srs && hrs && maps && out && stats && ws, -2, "hrn_get_loss_train: null argument");
+    HRN_CHECK(ws_bytes >= hrn_loss_train_workspace_bytes_impl(B), -3, "hrn_get_loss_train: workspace too small");
+    return hrn_launch_loss_train(srs, hrs, maps, B, S, crop, metric, out, stats, (double*)ws, (hipStream_t)stream);
+}
+
+int hrn_get_loss_backward(const float* srs, const float* hrs, const float* maps, const double* stats, const float* d_out, int B, int S,
+                          int crop, int metric, float* d_srs, void* stream) {
+    HRN_CHECK(B > 0 && B <= 65535 && S > 0 && crop >= 0 && 2 * crop < S, -2, "hrn_get_loss_backward: bad shape B=%d S=%d crop=%d", B, S, crop);
+    HRN_CHECK(metric == 1 || metric == 2, -2, "hrn_get_loss_backward: metric must be 1 (cMSE) or 2 (cPSNR)");
+    HRN_CHECK(srs && hrs && maps && stats && d_out && d_srs, -2, "hrn_get_loss_backward: null argument");
+    return hrn_launch_loss_backward(srs, hrs, maps, stats, d_out, B, S, crop, metric, d_srs, (hipStream_t)stream);
+}
+
 size_t hrn_shift_cpsnr_workspace_bytes(int B, int border) {
     if (B <= 0 || border < 0) return 0;
     return (size_t)B * (2 * border + 1) * (2 * border + 1) * sizeof(double);

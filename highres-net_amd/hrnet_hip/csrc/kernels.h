@@ -28,6 +28,12 @@ int hrn_launch_lanczos_shift_bwd(const float* img, const float* shift, const flo
 // ---- losses.hip
 int hrn_launch_masked_cmse(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out,
                            hipStream_t stream);
+// differentiable registered-loss tail (train.py:78-87, :183-187): forward keeps stats[B][4] = {n, bias, cMSE, 0} for the backward
+size_t hrn_loss_train_workspace_bytes_impl(int B);
+int hrn_launch_loss_train(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out,
+                          double* stats, double* partial, hipStream_t stream);
+int hrn_launch_loss_backward(const float* srs, const float* hrs, const float* maps, const double* stats, const float* d_out, int B,
+                             int S, int crop, int metric, float* d_srs, hipStream_t stream);
 int hrn_launch_shift_cpsnr(const float* srs, const float* hrs, const float* maps, int B, int S, int border, int clip,
                            double* scores, float* out, hipStream_t stream);
 

@@ -88,7 +88,92 @@ __global__ void shift_max_kernel(const double* __restrict__ scores, int nshift, 
     out[b] = (float)best;
 }
 
+// ---- the registered-loss tail of a training step, differentiable (train.py:78-87 and :183-187): forward in two stages (per-slice
+// fp64 partial sums, fixed-order finish: bit-reproducible), backward one elementwise pass.  With d = sr - hr, S0 = sum m,
+// S1 = sum m d, S2 = sum m d^2:  n = S0, b = -S1 / S0 (the brightness bias, DETACHED in the reference: train.py:83),
+// cMSE = (S2 - S1^2 / S0) / S0, and d cMSE / d sr_i = 2 m_i (d_i + b) / n.
+constexpr int LOSS_SPLIT = 16;      // slices per sample: B x 16 workgroups stream the three images once
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ srs, const float* __restrict__ hrs,
+                                                           const float* __restrict__ maps, int S, int crop, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const size_t n = (size_t)S * S;
+    const size_t per = (n + LOSS_SPLIT - 1) / LOSS_SPLIT;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    const float* sr = srs + (size_t)blockIdx.y * n;
+    const float* hr = hrs + (size_t)blockIdx.y * n;
+    const float* mp = maps + (size_t)blockIdx.y * n;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int y = (int)(i / S), x = (int)(i - (size_t)y * S);
+        float m = mp[i];
+        if (y < crop || y >= S - crop || x < crop || x >= S - crop) m = 0.f;
+        const double d = (double)sr[i] - (double)hr[i];
+        s0 += m; s1 += (double)m * d; s2 += (double)m * d * d;
+    }
+    s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        double* o = partial + ((size_t)blockIdx.y * LOSS_SPLIT + blockIdx.x) * 3;
+        o[0] = s0; o[1] = s1; o[2] = s2;
+    }
+}
+
+__global__ void loss_finish_kernel(const double* __restrict__ partial, int B, int metric, float* __restrict__ out, double* __restrict__ stats) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < LOSS_SPLIT; ++k) {
+        const double* o = partial + ((size_t)b * LOSS_SPLIT + k) * 3;
+        s0 += o[0]; s1 += o[1]; s2 += o[2];
+    }
+    const double cmse = (s2 - s1 * s1 / s0) / s0;
+    stats[4 * b + 0] = s0; stats[4 * b + 1] = -s1 / s0; stats[4 * b + 2] = cmse; stats[4 * b + 3] = 0.0;
+    out[b] = metric == 1 ? (float)cmse : (float)(-10.0 * log10(cmse));
+}
+
+__global__ __launch_bounds__(256) void loss_backward_kernel(const float* __restrict__ srs, const float* __restrict__ hrs,
+                                                            const float* __restrict__ maps, const double* __restrict__ stats,
+                                                            const float* __restrict__ d_out, int S, int crop, int metric,
+                                                            float* __restrict__ d_srs) {
+    const size_t n = (size_t)S * S;
+    const int b = blockIdx.y;
+    const double cnt = stats[4 * b + 0], bias = stats[4 * b + 1], cmse = stats[4 * b + 2];
+    // d out / d cMSE: cMSE itself -> 1;  -10 log10(cMSE) -> -10 / (ln 10 cMSE)
+    const double dm = metric == 1 ? 1.0 : -10.0 / (2.302585092994046 * cmse);
+    const float coef = (float)((double)d_out[b] * dm * 2.0 / cnt);
+    const float fb = (float)bias;
+    const size_t base = (size_t)b * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / S), x = (int)(i - (size_t)y * S);
+        float m = maps[base + i];
+        if (y < crop || y >= S - crop || x < crop || x >= S - crop) m = 0.f;
+        d_srs[base + i] = coef * m * (srs[base + i] - hrs[base + i] + fb);
+    }
+}
+
 }  // namespace
+
+size_t hrn_loss_train_workspace_bytes_impl(int B) { return (size_t)B * LOSS_SPLIT * 3 * sizeof(double); }
+
+int hrn_launch_loss_train(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out,
+                          double* stats, double* partial, hipStream_t stream) {
+    HrnProfScope prof("registered_loss_fwd", 0.0, 12.0 * B * S * S, stream);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_SPLIT, B), dim3(256), 0, stream, srs, hrs, maps, S, crop, partial);
+    HRN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, (const double*)partial, B, metric, out, stats);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_loss_backward(const float* srs, const float* hrs, const float* maps, const double* stats, const float* d_out, int B,
+                             int S, int crop, int metric, float* d_srs, hipStream_t stream) {
+    HrnProfScope prof("registered_loss_bwd", 0.0, 16.0 * B * S * S, stream);
+    int gx = (int)(((size_t)S * S + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(loss_backward_kernel, dim3(gx, B), dim3(256), 0, stream, srs, hrs, maps, stats, d_out, S, crop, metric, d_srs);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
 
 int hrn_launch_masked_cmse(const float* srs, const float* hrs, const float* maps, int B, int S, int crop, int metric, float* out,
                            hipStream_t stream) {

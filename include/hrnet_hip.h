@@ -168,6 +168,15 @@ int hrn_lanczos_shift_backward(const float* img, const float* shift, const float
  *                      clip != 0 clamps sr to [0,1] first (predict.py:43, train.py:212); workspace: B*(2b+1)^2 doubles.
  *                      Status maps are binary (Evaluator's formula squares the mask; identical for 0/1 maps). */
 int hrn_get_loss(const float* srs, const float* hrs, const float* hr_maps, int B, int S, int crop, int metric, float* out, void* stream);
+/* The same loss as the differentiable tail of a training step (src/train.py:183-187: loss = -get_loss(srs_shifted, hrs,
+ * mask, 'cPSNR')): hrn_get_loss_train also writes stats (B,4) f64 = {n, brightness bias b, cMSE, 0} per sample;
+ * hrn_get_loss_backward turns d_out (B) into d_srs (B,S,S) with b held constant, as the reference detaches it (train.py:83):
+ * d cMSE / d sr = 2 m (sr + b - hr) / n.  metric: 1 'cMSE' or 2 'cPSNR'.  workspace: fp64 partial sums (fixed-order: reproducible). */
+size_t hrn_get_loss_train_workspace_bytes(int B);
+int hrn_get_loss_train(const float* srs, const float* hrs, const float* hr_maps, int B, int S, int crop, int metric, float* out,
+                       double* stats, void* workspace, size_t workspace_bytes, void* stream);
+int hrn_get_loss_backward(const float* srs, const float* hrs, const float* hr_maps, const double* stats, const float* d_out, int B,
+                          int S, int crop, int metric, float* d_srs, void* stream);
 size_t hrn_shift_cpsnr_workspace_bytes(int B, int border);
 int hrn_shift_cpsnr(const float* srs, const float* hrs, const float* hr_maps, int B, int S, int border, int clip, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);

@@ -192,6 +192,74 @@ def main():
     except Exception as e:  # ordinary import error of an optional helper: record and continue
         print("callers golden skipped:", repr(e))
 
+    # ------------------------------------------------------------------ one full train step of the reference (train.py:164-190), fp64
+    train_step_golden(HRNet, ShiftNet)
+
+
+def train_step_golden(HRNet, ShiftNet):
+    """srs = fusion_model(lrs, alphas); shifts = register_batch(...); srs_shifted = apply_shifts(...); loss = -get_loss(..., 'cPSNR')
+    mean + lambda mean(shifts)^2; loss.backward() - the reference's own statements and modules, in fp64, train mode (BatchNorm batch
+    statistics; the dropout mask is injected through a forward hook so that the GPU test can feed the same one).  Stored: loss,
+    shifts, a crop of the SR image, and per parameter the gradient's L2 norm, sum and a strided sample (every tensor is far too
+    large to keep whole: fc1.weight alone is 33.5 M values); for the nine single-slope PReLUs and decode.final.bias additionally
+    sum |terms| of the gradient's defining sum (captured with module hooks), which is what bounds a float32 implementation's
+    error on those cancelling sums.  Inputs are regenerated from their seeds by the test."""
+    import train as ref_train
+    B, V, S, lam, crop_w = 2, 3, 48, 1e-6, 3
+    lrs, alphas, hrs = synth.make_batch(31, B, V, S, V)
+    rng = np.random.Generator(np.random.PCG64(5))
+    maps = (rng.random((B, 3 * S, 3 * S)) > 0.1).astype(np.float32)
+    keep = (rng.random((B, 32768)) >= 0.5)                                   # dropout keep-mask, reference flatten order
+    off = (3 * S - 128) // 2
+
+    fusion = HRNet(weights.HRNET_CONFIG).double().train()
+    fusion.load_state_dict({k: v.double() for k, v in weights.to_torch_state(weights.hrnet_state(1234)).items()})
+    regis = ShiftNet().double().train()
+    regis.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in weights.to_torch_state(weights.shiftnet_state(4321)).items()})
+    tmask = t(keep.astype(np.float64))
+    hk = regis.drop1.register_forward_hook(lambda m, i_, o: i_[0] * tmask / 0.5)      # dropout(p=0.5) with OUR mask
+
+    # sum |terms| of the scalar parameters' gradients: PReLU slope a: d a = sum g * min(x, 0);  decode.final.bias: sum g
+    abs_terms, hooks, saved = {}, [], {}
+    for name, mod in fusion.named_modules():
+        if isinstance(mod, torch.nn.PReLU):
+            hooks.append(mod.register_forward_hook(lambda m, i_, o, name=name: saved.__setitem__(name, i_[0].detach())))
+            hooks.append(mod.register_full_backward_hook(
+                lambda m, gi, go, name=name: abs_terms.__setitem__(name + ".weight", float((go[0] * saved[name].clamp(max=0)).abs().sum()))))
+    hooks.append(fusion.decode.final.register_full_backward_hook(
+        lambda m, gi, go: abs_terms.__setitem__("decode.final.bias", float(go[0].abs().sum()))))
+
+    t_lrs, t_alphas, t_hrs, t_maps = t(lrs).double(), t(alphas).double(), t(hrs).double(), t(maps).double()
+    torch_mask = ref_train.get_crop_mask(patch_size=S, crop_size=crop_w).double()
+    srs = fusion(t_lrs, t_alphas)
+    shifts = ref_train.register_batch(regis, srs[:, :, off:off + 128, off:off + 128],
+                                      reference=t_hrs[:, off:off + 128, off:off + 128].view(-1, 1, 128, 128))
+    srs_shifted = ref_train.apply_shifts(regis, srs, shifts, "cpu")[:, 0]
+    cropped_mask = torch_mask[0] * t_maps
+    loss = -ref_train.get_loss(srs_shifted, t_hrs, cropped_mask, metric="cPSNR")
+    loss = torch.mean(loss)
+    loss = loss + lam * torch.mean(shifts) ** 2
+    loss.backward()
+    hk.remove()
+    for h in hooks:
+        h.remove()
+
+    out = {"shape": np.asarray([B, V, S]), "lam": lam, "crop": crop_w, "loss": float(loss.detach()), "shifts": shifts.detach().numpy(),
+           "srs_crop": srs.detach().numpy()[:, :, 40:72, 40:72], "srs_shifted_crop": srs_shifted.detach().numpy()[:, 40:72, 40:72]}
+    for prefix, model in (("hrnet", fusion), ("shiftnet", regis)):
+        for k, p in model.named_parameters():
+            g = p.grad.detach().numpy().ravel()
+            stride = max(1, g.size // 2048)
+            out[f"{prefix}/{k}/norm"] = float(np.sqrt((g * g).sum()))
+            out[f"{prefix}/{k}/sum"] = float(g.sum())
+            out[f"{prefix}/{k}/absmax"] = float(np.abs(g).max())
+            out[f"{prefix}/{k}/stride"] = stride
+            out[f"{prefix}/{k}/sample"] = g[::stride].copy()
+            if prefix == "hrnet" and k in abs_terms:
+                out[f"{prefix}/{k}/abs_terms"] = abs_terms[k]
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+    print("train_step: loss", out["loss"], "shifts", shifts.detach().numpy().ravel(), "scalars with abs_terms:", sorted(abs_terms))
+
 
 if __name__ == "__main__":
     main()

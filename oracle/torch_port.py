@@ -42,3 +42,66 @@ def hrnet_forward(lrs, alphas, st, num_layers=2, alpha_residual=True):
     x = x.mean(1)
     x = F.prelu(F.conv_transpose2d(x, st["decode.deconv.0.weight"], st["decode.deconv.0.bias"], stride=3), st["decode.deconv.1.weight"])
     return F.conv2d(x, st["decode.final.weight"], st["decode.final.bias"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Ports of the training-only pieces, used by the gradient tests as the torch-autograd oracle (fp64 on the CPU) and pinned to the
+# reference's own train step by tests/golden/train_step.npz (tests/test_oracle_golden.py::test_train_step_port_matches_reference).
+
+
+def shiftnet_forward_train(x, st, keep_mask):
+    """ShiftNet.forward in train mode (ShiftNet.py:49-75: mean subtraction, 8 x conv + BatchNorm(batch statistics) + ReLU with
+    pools after layers 2 / 4 / 6, dropout p = 0.5 with the GIVEN keep-mask (B, 32768), fc1 + ReLU, fc2)."""
+    x = x - x.mean(dim=(2, 3), keepdim=True)
+    for i in range(1, 9):
+        x = F.conv2d(x, st[f"layer{i}.0.weight"], st[f"layer{i}.0.bias"], padding=1)
+        x = F.batch_norm(x, None, None, st[f"layer{i}.1.weight"], st[f"layer{i}.1.bias"], training=True, eps=1e-5)
+        x = F.relu(x)
+        if i in (2, 4, 6):
+            x = F.max_pool2d(x, 2)
+    x = x.reshape(x.shape[0], -1) * keep_mask * 2.0
+    x = F.relu(F.linear(x, st["fc1.weight"], st["fc1.bias"]))
+    return F.linear(x, st["fc2.weight"])
+
+
+def lanczos_shift(img, shift):
+    """lanczos.py:5-107: img (b, c, H, W), shift (c, 2) = (dy, dx) per channel; reflect pad 3, vertical then horizontal 7-tap
+    correlation with the un-windowed, renormalised Lanczos-3 taps (pi x == 0 -> 1e-6)."""
+    import math
+    c = img.shape[1]
+
+    def taps(d):
+        x = torch.linspace(-3, 3, 7, dtype=d.dtype).view(1, -1) - d.view(-1, 1)
+        t = math.pi * x
+        t = torch.where(t == 0, torch.tensor(1e-6, dtype=d.dtype), t)
+        k = torch.sin(t) / t * torch.sin(t / 3) / (t / 3)
+        return k / k.sum(1, keepdim=True)
+
+    ky, kx = taps(shift[:, 0]), taps(shift[:, 1])
+    pad = F.pad(img, (3, 3, 3, 3), mode="reflect")
+    out = F.conv2d(pad, ky.view(c, 1, 7, 1), groups=c)
+    return F.conv2d(out, kx.view(c, 1, 1, 7), groups=c)
+
+
+def registered_loss_cpsnr(srs, hrs, hr_maps):
+    """get_loss(..., metric='cPSNR') of train.py:66-87: brightness bias detached."""
+    nclear = torch.sum(hr_maps, dim=(1, 2))
+    bright = torch.sum(hr_maps * (hrs - srs), dim=(1, 2)).clone().detach() / nclear
+    loss = torch.sum(hr_maps * (srs + bright.view(-1, 1, 1) - hrs) ** 2, dim=(1, 2)) / nclear
+    return -10 * torch.log10(loss)
+
+
+def train_step(lrs, alphas, hrs, hr_maps, keep_mask, hst, sst, lam=1e-6, crop=3):
+    """One optimisation step's loss of train.py:172-187 (n_views of the SR = 1) from state dicts that may require grad:
+    -> (loss scalar, shifts (B,1,2), srs (B,1,3S,3S), srs_shifted (B,3S,3S))."""
+    s3 = 3 * lrs.shape[-1]
+    off = (s3 - 128) // 2
+    srs = hrnet_forward.__wrapped__(lrs, alphas, hst)
+    ref = hrs[:, off:off + 128, off:off + 128].reshape(-1, 1, 128, 128)
+    shifts = torch.stack([shiftnet_forward_train(torch.cat([ref, srs[:, :, off:off + 128, off:off + 128]], 1), sst, keep_mask)], 1)
+    shifted = lanczos_shift(srs.reshape(-1, 1, s3, s3).transpose(0, 1), shifts.reshape(-1, 2).flip(-1))[:, None].reshape(-1, 1, s3, s3)[:, 0]
+    cm = torch.ones((s3, s3), dtype=hrs.dtype)
+    cm[:crop] = 0; cm[-crop:] = 0; cm[:, :crop] = 0; cm[:, -crop:] = 0
+    loss = -registered_loss_cpsnr(shifted, hrs, cm * hr_maps)
+    loss = loss.mean() + lam * shifts.mean() ** 2
+    return loss, shifts, srs, shifted

@@ -142,6 +142,51 @@ def test_full_size_properties(prec, b, v):
         assert util.rel_err(y0[:1].cpu().numpy(), want) <= 1e-4
 
 
+def test_config5_full_size_properties():
+    """BASELINE configs[4] at its full size: B=32, n_views=32, 512x512 -> 1536x1536, bf16 (1 GiB of input, 96 GiB of workspace on
+    the 288 GB part).  The oracle cannot run this; the bit-exact properties of `test_full_size_properties` can: determinism,
+    batch independence, invariance to the content of padded views, and alpha really gating."""
+    b, v, s = 32, 32, 512
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip(f"needs ~100 GiB of device memory, {free / 2 ** 30:.0f} GiB free")
+    lrs, alphas = synth.fast_batch(55, b, v, s)
+    n_real = v - 5
+    alphas[:, n_real:] = 0.0
+    lrs[:, n_real:] = 0.0
+    m = util.hip_hrnet("bf16")
+    x, a = util.dev(lrs), util.dev(alphas)
+    del lrs
+    with torch.no_grad():
+        y0 = m(x, a).clone()
+        assert y0.shape == (b, 1, 3 * s, 3 * s) and bool(torch.isfinite(y0).all())
+        assert torch.equal(m(x, a), y0)                                         # deterministic
+        one = m(x[7:8].contiguous(), a[7:8].contiguous())
+        assert torch.equal(one[0], y0[7])                                       # a sample alone == the sample in the batch
+        x[:, n_real:] = torch.rand_like(x[:, n_real:])
+        assert torch.equal(m(x, a), y0)                                         # padded views (alpha 0) do not matter
+        a[:, n_real:] = 1.0
+        assert not torch.equal(m(x, a), y0)                                     # ... because alpha gates them
+    from hrnet_hip import binding
+    binding._ws_cache.clear()                                                   # hand the 96 GiB back before the next test
+    torch.cuda.empty_cache()
+
+
+def test_config5_image_size_fp32_vs_oracle():
+    """The fp32 path at configs[4]'s image size against the oracle itself (one sample, two views: what the oracle does in
+    ~20 s), and the bf16 path against the same oracle output: the 512 x 512 tiling (32 x 16 tiles per image, in-image byte
+    offsets up to 64 MB) is checked against the reference's arithmetic, not only against our own other path."""
+    lrs, alphas = synth.fast_batch(77, 1, 2, 512)
+    want = O.hrnet_forward(lrs, alphas, weights.hrnet_state(1234), dtype=np.float32)
+    x, a = util.dev(lrs), util.dev(alphas)
+    with torch.no_grad():
+        got32 = util.hip_hrnet("fp32")(x, a).cpu().numpy()
+        got16 = util.hip_hrnet("bf16")(x, a).cpu().numpy()
+    assert got32.shape == want.shape == (1, 1, 1536, 1536)
+    assert util.rel_err(got32, want) <= 1e-4
+    _check("bf16", got16, want)
+
+
 # ----------------------------------------------------------------------------- ShiftNet
 def test_shiftnet_eval_vs_reference_golden():
     g = util.golden("shiftnet_eval_b3")

@@ -125,3 +125,45 @@ def test_torch_cpu_port_matches_reference(golden_dir, name):
     sr = torch_port.hrnet_forward(torch.from_numpy(g["lrs"]), torch.from_numpy(g["alphas"]), st,
                                   alpha_residual=bool(g["alpha_residual"])).numpy()
     assert rel_err(sr, g["sr"]) < 1e-5
+
+
+def test_train_step_port_matches_reference(golden_dir):
+    """The torch port the gradient tests use as their autograd oracle (oracle/torch_port.train_step, fp64) against ONE FULL TRAIN
+    STEP OF THE REFERENCE ITSELF (oracle/make_goldens.py::train_step_golden: train.py:164-190 on the reference's modules, fp64,
+    hooked dropout mask): loss, shifts, SR crops and every parameter gradient (L2 norm, sum, strided sample)."""
+    import torch
+    from oracle import torch_port
+    g = load(golden_dir, "train_step")
+    B, V, S = (int(v) for v in g["shape"])
+    lrs, alphas, hrs = synth.make_batch(31, B, V, S, V)
+    rng = np.random.Generator(np.random.PCG64(5))
+    maps = (rng.random((B, 3 * S, 3 * S)) > 0.1).astype(np.float32)
+    keep = (rng.random((B, 32768)) >= 0.5)
+    hst = {k: v.double().requires_grad_(True) for k, v in weights.to_torch_state(weights.hrnet_state(1234)).items()}
+    sst = {k: v.double().requires_grad_("running" not in k and "num_batches" not in k) for k, v in weights.to_torch_state(weights.shiftnet_state(4321)).items()}
+    torch.set_num_threads(8)
+    with torch.enable_grad():
+        loss, shifts, srs, shifted = torch_port.train_step(torch.from_numpy(lrs).double(), torch.from_numpy(alphas).double(),
+                                                          torch.from_numpy(hrs).double(), torch.from_numpy(maps).double(),
+                                                          torch.from_numpy(keep).double(), hst, sst, lam=float(g["lam"]), crop=int(g["crop"]))
+        loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-10 * abs(float(g["loss"]))
+    assert rel_err(shifts.detach().numpy(), g["shifts"]) <= 1e-9
+    assert rel_err(srs.detach().numpy()[:, :, 40:72, 40:72], g["srs_crop"]) <= 1e-10
+    assert rel_err(shifted.detach().numpy()[:, 40:72, 40:72], g["srs_shifted_crop"]) <= 1e-9
+    for prefix, st in (("hrnet", hst), ("shiftnet", sst)):
+        for k, v in st.items():
+            if not v.requires_grad:
+                continue
+            got = v.grad.numpy().ravel()
+            stride = int(g[f"{prefix}/{k}/stride"])
+            scale = max(float(g[f"{prefix}/{k}/absmax"]), 1e-300)
+            if prefix == "shiftnet" and k.endswith(".0.bias"):
+                continue                # conv bias in front of a train-mode BatchNorm: a mathematically zero gradient (rounding noise)
+            tol = 1e-7 * scale
+            if f"{prefix}/{k}/abs_terms" in g.files:       # a cancelling sum (decode.final.bias: exactly zero by the brightness correction)
+                tol = 1e-9 * float(g[f"{prefix}/{k}/abs_terms"])
+            assert np.abs(got[::stride] - g[f"{prefix}/{k}/sample"]).max() <= tol, (prefix, k)
+            if f"{prefix}/{k}/abs_terms" in g.files:
+                continue
+            assert abs(np.sqrt((got * got).sum()) - float(g[f"{prefix}/{k}/norm"])) <= 1e-7 * max(float(g[f"{prefix}/{k}/norm"]), 1e-300), (prefix, k)
