@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py - SR frames/s of the MI355X HighRes-net forward (BASELINE.json metric) + roofline + CPU baseline.
+"""bench.py - SR frames/s of the MI355X HighRes-net forward (BASELINE.json metric) + parity + rooflines + CPU baseline.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -8,11 +8,21 @@
 A "step" is ONE HRNet.forward(lrs, alphas) on one resident batch of the workload the metric is quoted on
 (BASELINE.json configs[2]: B=32, n_views=32, 128x128 -> 384x384, bf16 storage / fp32 accumulation).  With N GPUs
 every rank runs its own batch (weak scaling, no data-path collective: SURVEY.md section 8e); `value` = N*B*K / max-over-ranks
-wall time.  Rank 0 prints one JSON line with the contract keys plus `roofline` (dominant kernel, measured live with
-the library's hipEvent profiler over extra instrumented steps) and `cpu_baseline` (own torch-CPU port of the same
-forward on a bounded sample of the same workload, host cores stated; N=1 only).
+wall time.  Rank 0 prints one JSON line with the contract keys plus
+  roofline      dominant kernel family (MFMA bound), measured live with the library's hipEvent profiler over extra steps
+  roofline_hbm  the recursive-fusion stage against the HBM roof (north_star): SURVEY 8d's algorithmic bytes / its measured time
+  parity        the metric's second half ("cPSNR vs reference"): the timed bf16 output against the exact-fp32 HIP path on the same
+                batch, and (N=1) both HIP paths against the torch-CPU port on the cpu_baseline sample
+  fp32_path / c2_fp32 / train_step   extra measurements: the exact-fp32 path at the metric's shape, BASELINE configs[1]
+                (B=16, V=16, fp32), and one optimisation step of src/train.py at the reference's training shape
+  cpu_baseline  own torch-CPU port of the same forward on a bounded sample of the same workload, host cores stated (N=1 only).
+
+    python bench.py --mode train [--gpus N] ...   BASELINE configs[3]: the data-parallel optimisation step of src/train.py:164-191
+on the HIP modules (per-rank B=32, 32 views, 64x64 patches, fp32), FusedAdam, gradient exchange over RCCL with ShiftNet's 137 MB
+slice all-reduced from a backward hook under HRNet's backward; value = samples/s over all ranks.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,6 +43,8 @@ NETWORK = {   # reference config/config.json:8-34
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
+FUSION_FAMILIES = ("conv3x3_bf16_128x128", "conv3x3_bf16_128x128+res", "conv3x3_bf16_128x64+res", "conv3x3_bf16_128x64")
+KERNEL_SOURCES = ("conv3x3_v6.hip", "conv3x3_v7.hip", "conv3x3_r64.hip", "stem.hip", "decoder.hip")
 
 
 def synth_inputs(batch, views, size, device, seed):
@@ -57,10 +69,53 @@ def flops_per_frame(views, size):
     return views * enc + pairs * pair + dec
 
 
-def cpu_baseline(views, size, budget_s=20.0):
-    """Time the torch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload."""
-    from oracle import torch_port, weights
-    st = weights.to_torch_state(weights.hrnet_state(1234))
+def fusion_units(views):
+    """algorithmic bytes of the recursive fusion = sum over levels of (2h read + h write) units of 64*HW*es."""
+    n, units = views, 0
+    while n // 2 > 0:
+        units += 3 * (n // 2)
+        n //= 2
+    return units
+
+
+def kernel_source_hash():
+    h = hashlib.sha1()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "highres-net_amd", "hrnet_hip", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def precomputed_traffic(batch, views, size, precision):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes of tools/prof_all.sh (FETCH_SIZE doubled per the gfx950 note,
+    + WRITE_SIZE), committed as profiles/r02_traffic.json together with a hash of the kernel sources they were taken on: stale or
+    foreign numbers are not reported."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        w = tj["workload"]
+        if (w["batch"], w["views"], w["size"], w["precision"]) != (batch, views, size, precision):
+            return None
+        if tj.get("kernel_source_hash") != kernel_source_hash():
+            return None
+        return tj
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpsnr_np(a, b):
+    """Evaluator.cPSNR (Evaluator.py:34-38) with an all-ones mask: brightness-corrected PSNR of a against b, mean over the batch."""
+    import numpy as np
+    a = a.reshape(a.shape[0], -1).astype(np.float64)
+    b = b.reshape(b.shape[0], -1).astype(np.float64)
+    bias = (b - a).mean(1, keepdims=True)
+    cmse = ((a + bias - b) ** 2).mean(1)
+    return float((-10.0 * np.log10(np.maximum(cmse, 1e-300))).mean())
+
+
+def cpu_baseline(net_bf16, net_fp32, binding, views, size, budget_s=20.0):
+    """Time the torch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload, and check both HIP paths against
+    its output on that very sample (the oracle as the checker, never as the thing measured on the GPU side)."""
+    from oracle import torch_port
+    st = {k: v.detach().float().cpu() for k, v in net_fp32.state_dict().items()}
     threads = torch.get_num_threads()
     lrs, alphas = synth_inputs(1, views, size, "cpu", 5)
     t0 = time.perf_counter()
@@ -69,11 +124,79 @@ def cpu_baseline(views, size, budget_s=20.0):
     n = int(max(1, min(8, budget_s // max(one, 1e-3))))
     lrs, alphas = synth_inputs(n, views, size, "cpu", 6)
     t0 = time.perf_counter()
-    torch_port.hrnet_forward(lrs, alphas, st)
+    want = torch_port.hrnet_forward(lrs, alphas, st).numpy()
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "SR frames/s", "cores": threads, "kind": "port",
-            "sample": f"B={n} of the B=32 batch, n_views={views}, {size}x{size}->{3 * size}x{3 * size}, fp32, own torch-CPU port "
-                      f"of HRNet.forward (oracle/torch_port.py), {threads} threads, {dt:.1f} s"}
+    out = {"value": round(n / dt, 4), "unit": "SR frames/s", "cores": threads, "kind": "port",
+           "sample": f"B={n} of the B=32 batch, n_views={views}, {size}x{size}->{3 * size}x{3 * size}, fp32, own torch-CPU port "
+                     f"of HRNet.forward (oracle/torch_port.py), {threads} threads, {dt:.1f} s"}
+    parity = {}
+    with torch.no_grad():
+        for name, net in (("bf16", net_bf16), ("fp32", net_fp32)):
+            got = net(lrs.cuda(), alphas.cuda()).cpu().numpy()
+            import numpy as np
+            parity[name] = {"max_rel": float(np.abs(got - want).max() / np.abs(want).max()), "cpsnr_db": round(cpsnr_np(got, want), 2)}
+    return out, parity
+
+
+def timed(step, steps, warmup, device, hdist):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device)
+    hdist.barrier(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    hdist.barrier(device)
+    return hdist.max_over_ranks(time.perf_counter() - t0, device)
+
+
+def timed_local(step, steps, warmup, device):
+    """Rank-local timing (no barrier): for the extra measurements only rank 0 takes."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    return time.perf_counter() - t0
+
+
+def make_train_step(device, batch, views, patch, overlap=True):
+    """The statements of src/train.py:164-191 on the HIP modules (random-init weights, synthetic batch)."""
+    from DeepNetworks.HRNet import HRNet
+    from DeepNetworks.ShiftNet import ShiftNet
+    from hrnet_hip import losses
+    from hrnet_hip.optim import FusedAdam
+    torch.manual_seed(1234)
+    fusion = HRNet(dict(NETWORK)).to(device).train()
+    regis = ShiftNet().to(device).train()
+    with torch.no_grad():
+        regis.fc2.weight.normal_(0.0, 1e-3)                       # not the all-zero start: the registration branch does real work
+    params = list(fusion.parameters()) + list(regis.parameters())
+    opt = FusedAdam(params, lr=1e-4, overlap_early=list(regis.parameters()) if overlap else None)
+    lrs, alphas = synth_inputs(batch, views, patch, device, seed=200 + int(os.environ.get("RANK", 0)))
+    g = torch.Generator(device="cpu").manual_seed(7)
+    hrs = (torch.rand((batch, 3 * patch, 3 * patch), generator=g) * 0.25).to(device)
+    maps = torch.ones((batch, 3 * patch, 3 * patch), device=device)
+    off = (3 * patch - 128) // 2
+
+    def step(exchange=True):
+        opt.zero_grad()
+        srs = fusion(lrs, alphas)                                                                   # train.py:174
+        ref = hrs[:, off:off + 128, off:off + 128].reshape(-1, 1, 128, 128)
+        shifts = torch.stack([regis(torch.cat([ref, srs[:, :, off:off + 128, off:off + 128]], 1))], 1)   # register_batch :177-179
+        b, n, h, w = srs.shape
+        shifted = regis.transform(shifts.view(-1, 2), srs.view(-1, 1, h, w), device=device).view(-1, n, h, w)[:, 0]   # apply_shifts
+        loss = -losses.get_loss(shifted, hrs, maps, metric="cPSNR", crop=3)                         # :183-185, crop mask folded in
+        loss = torch.mean(loss) + 1e-6 * torch.mean(shifts) ** 2                                    # :186-187
+        loss.backward()                                                                             # :190
+        if exchange:
+            opt.allreduce()                                                                         # the one exchange step (SURVEY 8e)
+        opt.step()                                                                                  # :191
+        return loss
+    return step
 
 
 def main():
@@ -81,24 +204,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"])
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--views", type=int, default=32)
-    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--size", type=int, default=128, help="LR side (forward mode)")
+    ap.add_argument("--patch", type=int, default=64, help="LR patch side (train mode; config.json patch_size)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--profile-steps", type=int, default=3, help="extra instrumented steps for the roofline (not in `value`)")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra instrumented steps for the rooflines (not in `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / config-2 / train-step extra measurements")
     args = ap.parse_args()
 
     from hrnet_hip import binding, dist as hdist
     from DeepNetworks.HRNet import HRNet
 
-    rank, local_rank, ws = hdist.init()
+    rank, local_rank, ws = hdist.init()            # joins the process group BEFORE any GPU call of this process
     if ws != args.gpus and ws > 1:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {ws}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the HIP path has no CPU fallback")
     device = torch.device("cuda", local_rank if ws > 1 else 0)
     torch.cuda.set_device(device)
+
+    if args.mode == "train":
+        step = make_train_step(device, args.batch, args.views, args.patch)
+        steps = max(1, min(args.steps, 10))
+        warm = max(1, min(args.warmup, 3))
+        elapsed = timed(step, steps, warm, device, hdist)
+        no_x = timed(lambda: step(exchange=False), steps, 1, device, hdist) if ws > 1 else elapsed
+        if rank == 0:
+            print(json.dumps({
+                "metric": "train samples/sec of the src/train.py optimisation step (B=32/GPU, n_views=32, 64x64 patches)",
+                "value": round(args.batch * ws * steps / elapsed, 2), "unit": "samples/s", "n_gpus": ws, "steps": steps, "warmup": warm,
+                "ms_per_step": round(elapsed / steps * 1e3, 2), "ms_per_step_without_exchange": round(no_x / steps * 1e3, 2),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"train.py:164-191 on the HIP modules: HRNet + ShiftNet + Lanczos + registered cPSNR loss + FusedAdam, "
+                                       f"B={args.batch}/GPU, n_views={args.views}, {args.patch}x{args.patch} patches (BASELINE configs[3])",
+                           "global_batch": args.batch * ws,
+                           "parallelism": f"dp{ws}: RCCL all-reduce of 139 MB of fp32 gradients per step, ShiftNet's slice overlapped with HRNet's backward",
+                           "weights": "random init (seed 1234), fc2 ~ N(0, 1e-3)"}}), flush=True)
+        hdist.finalize()
+        return
 
     torch.manual_seed(1234)                               # same random-init weights on every rank
     net = HRNet(dict(NETWORK, precision=args.precision)).to(device).eval()
@@ -110,21 +256,11 @@ def main():
         binding.hrnet_forward(packed, dt, 2, True, lrs, alphas, out=sr)
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize(device)
-        hdist.barrier(device)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(device)
-        hdist.barrier(device)
-        elapsed = time.perf_counter() - t0
-    elapsed = hdist.max_over_ranks(elapsed, device)
+        elapsed = timed(step, args.steps, args.warmup, device, hdist)
     frames = args.batch * args.steps * ws
     value = frames / elapsed
 
-    roofline, kernels = None, {}
+    roofline, roofline_hbm, kernels, parity, extras = None, None, {}, {}, {}
     if rank == 0:
         # instrumented steps: hipEvent pair around every kernel launch, on the launch stream (torch's current stream)
         binding.profile_enable(True)
@@ -134,37 +270,86 @@ def main():
         torch.cuda.synchronize(device)
         binding.profile_enable(False)
         prof = binding.profile_read()
+        nprof = max(1, args.profile_steps)
         total_ms = sum(v["ms"] for v in prof.values()) or 1.0
         for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
             avg = v["ms"] / max(v["launches"], 1)
-            kernels[name] = {"launches_per_step": v["launches"] // max(1, args.profile_steps), "avg_ms": round(avg, 4),
+            kernels[name] = {"launches_per_step": v["launches"] // nprof, "avg_ms": round(avg, 4),
                              "share": round(v["ms"] / total_ms, 4),
                              "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] > 0 else None,
                              "gbs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] > 0 else None}
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        name, v = dom
+        name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = v["flops"] / v["ms"] / 1e9            # TFLOP/s: algorithmic FLOPs of the launches / their summed duration
         peak = PEAK_TFLOPS[args.precision]
-        # HBM bytes per (average) launch come from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
-        # note, + WRITE_SIZE) committed in profiles/r01_traffic.json; null when this run is not that workload
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            w = tj["workload"]
-            if (w["batch"], w["views"], w["size"], w["precision"]) == (args.batch, args.views, args.size, args.precision):
-                traffic = tj["bytes_per_launch"].get(name)
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        tj = precomputed_traffic(args.batch, args.views, args.size, args.precision)
+        traffic = tj["bytes_per_launch"].get(name) if tj else None
         roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_source": "precomputed: profiles/r02_traffic.json (rocprofv3 --pmc passes of tools/prof_all.sh on these kernel sources)" if traffic else None,
                     "bytes_per_launch_algorithmic": v["bytes"] / max(v["launches"], 1),
                     "launches": v["launches"], "avg_launch_ms": round(v["ms"] / max(v["launches"], 1), 4),
                     "flops_per_launch": v["flops"] / max(v["launches"], 1),
                     "algorithmic_gbs": round(v["bytes"] / v["ms"] / 1e6, 1)}
+        # the recursive fusion as ONE operator against the HBM roof (north_star): SURVEY 8d's algorithmic bytes = units of
+        # 64*HW*es (2h read + h write per level) per sample; measured time = all its conv launches of the instrumented steps
+        fus = [prof[f] for f in FUSION_FAMILIES if f in prof]
+        if fus and args.precision == "bf16":
+            fus_ms = sum(f["ms"] for f in fus) / nprof
+            alg = fusion_units(args.views) * 64 * args.size * args.size * 2 * args.batch
+            layer_bytes = sum(f["bytes"] for f in fus) / nprof
+            ctr = sum(tj["bytes_per_launch"].get(k, 0) * kernels[k]["launches_per_step"] for k in FUSION_FAMILIES if tj and k in kernels) if tj else None
+            roofline_hbm = {"stage": "recursive fusion (all levels of one forward)", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                            "achieved": round(alg / fus_ms / 1e6, 1), "frac": round(alg / fus_ms / 1e6 / PEAK_HBM_GBS, 4),
+                            "algorithmic_bytes": alg, "ms": round(fus_ms, 3),
+                            "per_layer_algorithmic_bytes": layer_bytes, "per_layer_algorithmic_gbs": round(layer_bytes / fus_ms / 1e6, 1),
+                            "traffic": ctr, "traffic_gbs": round(ctr / fus_ms / 1e6, 1) if ctr else None,
+                            "note": "the stage is MFMA-bound (~1000 FLOP/B): its HBM fraction states how far the conv-per-launch "
+                                    "decomposition is from the fused operator's minimal traffic, not a saturated memory system"}
+
+        # ---- parity of the run that was timed: bf16 output vs the exact-fp32 HIP path on the same batch (cPSNR: Evaluator.py:34-38, all-ones mask)
+        with torch.no_grad():
+            other = "fp32" if args.precision == "bf16" else "bf16"
+            net.precision = other
+            p2, d2 = net.packed_parameters()
+            ref = binding.hrnet_forward(p2, d2, 2, True, lrs, alphas)
+            net.precision = args.precision
+            a, b = (sr, ref) if args.precision == "bf16" else (ref, sr)                 # a: bf16, b: fp32
+            ones = torch.ones_like(a[:, 0])
+            parity["bf16_vs_fp32_hip_path"] = {
+                "max_rel": float((a - b).abs().max() / b.abs().max()),
+                "cpsnr_db": round(float(binding.get_loss(a[:, 0], b[:, 0], ones, "cPSNR").mean()), 2),
+                "batch": f"the timed batch (B={args.batch}, n_views={args.views})"}
+            if not args.no_extras:
+                # the exact-fp32 path at the metric's shape (the path that meets the 1e-3 contract) and BASELINE configs[1]
+                def fstep():
+                    binding.hrnet_forward(p2 if other == "fp32" else packed, binding.F32, 2, True, lrs, alphas, out=sr)
+                t = timed_local(fstep, 3, 1, device) / 3
+                extras["fp32_path"] = {"frames_per_s": round(args.batch / t, 1), "ms_per_step": round(t * 1e3, 2), "steps": 3,
+                                       "workload": f"B={args.batch}, n_views={args.views}, exact-fp32 MFMA"}
+                l2, a2 = synth_inputs(16, 16, 128, device, seed=300)
+                s2 = torch.empty((16, 1, 384, 384), dtype=torch.float32, device=device)
+                pf = p2 if other == "fp32" else packed
+
+                def c2step():
+                    binding.hrnet_forward(pf, binding.F32, 2, True, l2, a2, out=s2)
+                t = timed_local(c2step, 5, 2, device) / 5
+                extras["c2_fp32"] = {"frames_per_s": round(16 / t, 1), "ms_per_step": round(t * 1e3, 2), "steps": 5,
+                                     "workload": "BASELINE configs[1]: B=16, n_views=16, 128x128->384x384, fp32"}
+                step()                                   # leave `sr` holding the timed path's output again
+        if not args.no_extras and ws == 1:
+            binding._ws_cache.clear()
+            torch.cuda.empty_cache()
+            tstep = make_train_step(device, 32, 32, 64)
+            t = timed_local(tstep, 3, 2, device) / 3
+            extras["train_step"] = {"ms_per_step": round(t * 1e3, 1), "samples_per_s": round(32 / t, 1), "steps": 3,
+                                    "workload": "src/train.py:164-191 on the HIP modules, B=32, n_views=32, 64x64 patches, fp32 (python bench.py --mode train)"}
 
     cpu = None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.views, args.size)
+        net32 = HRNet(dict(NETWORK, precision="fp32")).to(device).eval()
+        net32.load_state_dict(net.state_dict())
+        cpu, vs_port = cpu_baseline(net, net32, binding, args.views, args.size)
+        parity["vs_cpu_port_on_cpu_baseline_sample"] = vs_port
 
     if rank == 0:
         tf = flops_per_frame(args.views, args.size) * value / 1e12
@@ -178,8 +363,9 @@ def main():
                        "global_batch": args.batch * ws, "parallelism": f"dp{ws} replicas, no data-path collective",
                        "weights": "random init (torch default, seed 1234)"},
             "whole_forward_tflops": round(tf, 1),
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "parity": parity, "cpu_baseline": cpu, "kernels": kernels,
         }
+        line.update(extras)
         print(json.dumps(line), flush=True)
     hdist.finalize()
 

@@ -96,8 +96,33 @@ class _HRNetTrainFunction(torch.autograd.Function):
         named = dict(zip(ctx.names, params))
         grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in named.items()}
         binding.hrnet_backward(ctx.packed, named, grads, ctx.module._num_layers, ctx.module.fuse.alpha_residual, lrs, alphas,
-                               d_sr.contiguous(), ctx.tws)
-        ctx.tws = None
+                               d_sr.contiguous(), ctx.tws)          # ctx.tws stays: backward(retain_graph=True) may come again
+        return (None, None, None, None) + tuple(grads[k].to(named[k].dtype) for k in ctx.names)
+
+
+class _HRNetLazyTrainFunction(torch.autograd.Function):
+    """`.train()` mode with `precision="bf16"`: the forward runs the bf16 INFERENCE kernels (what `precision` asks for; this is
+    the path `src/predict.py` takes, whose `load_model` never calls `.eval()` and whose `get_sr_and_score` does not use
+    `no_grad`: predict.py:86-100, :17-49) and keeps nothing; IF a backward pass follows, it re-runs the forward on the fp32
+    training kernels first (hrn_hrnet_forward_train) and then hrn_hrnet_backward.  Gradients are those of the fp32 model at the
+    same parameters; the one returned tensor carries bf16 rounding."""
+
+    @staticmethod
+    def forward(ctx, module, names, lrs, alphas, *params):
+        packed, dt = module.packed_parameters()
+        ctx.module, ctx.names = module, names
+        ctx.save_for_backward(lrs, alphas, *params)
+        return binding.hrnet_forward(packed, dt, module._num_layers, module.fuse.alpha_residual, lrs, alphas)
+
+    @staticmethod
+    def backward(ctx, d_sr):
+        lrs, alphas, *params = ctx.saved_tensors
+        m = ctx.module
+        packed = m._packed_f32()
+        _, tws = binding.hrnet_forward_train(packed, lrs, alphas, m._num_layers, m.fuse.alpha_residual)
+        named = dict(zip(ctx.names, params))
+        grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in named.items()}
+        binding.hrnet_backward(packed, named, grads, m._num_layers, m.fuse.alpha_residual, lrs, alphas, d_sr.contiguous(), tws)
         return (None, None, None, None) + tuple(grads[k].to(named[k].dtype) for k in ctx.names)
 
 
@@ -138,11 +163,16 @@ class HRNet(nn.Module):
             raise ValueError("square low-res images only: the reference reinterprets (H,W) as (W,H) in its .view() "
                              "(HRNet.py:204), which is the identity only for H == W")
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training path (.train() mode with grad enabled; fp32 kernels whatever `precision` says): a forward that keeps its
-            # intermediates + the HIP backward.  In .eval() mode (validation, train.py:196-215; predict.py) the inference
-            # kernels run and the result carries no autograd graph.
+            # .train() mode with grad enabled - the training loop (train.py:160-190), but also src/predict.py, which never calls
+            # .eval() and uses no no_grad (predict.py:86-100, :17-49).  Autograd cannot tell us whether a backward pass will follow:
+            #   precision "fp32" (default): the fp32 training forward, which keeps its intermediates for the HIP backward (same
+            #                               numbers as the fp32 inference kernels);
+            #   precision "bf16":           the bf16 inference kernels, as asked for; a backward pass, if one comes, first
+            #                               recomputes the forward on the fp32 training kernels (_HRNetLazyTrainFunction).
+            # In .eval() mode (validation, train.py:196-215) the inference kernels run and the result carries no autograd graph.
             names = [k for k, _ in self.named_parameters()]
-            return _HRNetTrainFunction.apply(self, names, lrs.detach(), alphas.detach(), *[p for _, p in self.named_parameters()])
+            fn = _HRNetLazyTrainFunction if self._dtype() == binding.BF16 else _HRNetTrainFunction
+            return fn.apply(self, names, lrs.detach(), alphas.detach(), *[p for _, p in self.named_parameters()])
         packed, dt = self.packed_parameters()
         return binding.hrnet_forward(packed, dt, self._num_layers, self.fuse.alpha_residual, lrs.detach(), alphas.detach())
 

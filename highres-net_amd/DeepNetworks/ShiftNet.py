@@ -35,7 +35,6 @@ class _ShiftNetTrainFunction(torch.autograd.Function):
         grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in zip(ctx.names, params)}
         d_x = binding.shiftnet_backward(named, grads, x.detach(), ctx.mask, d_theta.contiguous(), ctx.tws,
                                         need_input_grad=ctx.needs_input_grad[3])
-        ctx.tws = None
         return (None, None, None, d_x) + tuple(grads[k] for k in ctx.names)
 
 

@@ -239,8 +239,7 @@ int hrn_hrnet_forward(const void* packed, int dt, int nl, int alpha_residual, co
     // independent).  HRN_SLICE_MB = per-buffer budget in MiB; default 0 = whole batch in one go: measured at c3 the
     // kernels are not HBM-bound yet and the smaller launches cost more in tails than residency gains (r01: 34.4 ms
     // at 64 MiB slices vs 27.7 ms unsliced), so it stays a knob for later rounds.
-    static long slice_mb = -1;
-    if (slice_mb < 0) { const char* e = getenv("HRN_SLICE_MB"); slice_mb = e ? atol(e) : 0; }
+    static const long slice_mb = [] { const char* e = getenv("HRN_SLICE_MB"); return e ? atol(e) : 0L; }();     // read once (thread-safe init)
     const size_t per_sample = (size_t)V * H * W * 64 * hrn_esize(dt);
     int bs = B;
     if (slice_mb > 0) {

@@ -18,6 +18,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;   // 8 bytes = 4 bf1
 void hrn_set_error(const char* fmt, ...);
 // allow `kernel` to use `bytes` of dynamic LDS on the current device (set once per device; prof.hip)
 int hrn_allow_lds(const void* kernel, int bytes);
+// compute units of the current device, cached per device (prof.hip)
+int hrn_device_cus(void);
 #define HRN_CHECK(cond, code, ...)                                \
     do {                                                          \
         if (!(cond)) { hrn_set_error(__VA_ARGS__); return (code); } \

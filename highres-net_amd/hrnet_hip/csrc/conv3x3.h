@@ -35,12 +35,6 @@ int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream
 // bf16 64 -> 64 with LDS-resident weights (conv3x3_r64.hip); -100 = not applicable, caller picks another kernel.
 int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream);
 
-// bf16 128 -> {128, 64} on 512-pixel tiles with LDS-DMA staging (conv3x3_v4.hip); -100 = not applicable.
-int hrn_launch_conv3x3_v4(int cout, const ConvParams& p, hipStream_t stream);
-
-// bf16 128 -> 128, the v4 structure on v_mfma_f32_16x16x32_bf16 (conv3x3_v5.hip); -100 = not applicable.
-int hrn_launch_conv3x3_v5(const ConvParams& p, hipStream_t stream);
-
 // bf16 128 -> {128, 64}, round 2: descriptor-based halo DMA issued from the MFMA gaps, LDS-staged epilogue (conv3x3_v6.hip);
 // -100 = not applicable.
 int hrn_launch_conv3x3_v6(int cout, const ConvParams& p, hipStream_t stream);

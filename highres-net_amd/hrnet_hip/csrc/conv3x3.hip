@@ -313,22 +313,15 @@ __global__ __launch_bounds__(256 * (COUT / 64), 2) void conv3x3_kernel(const Con
     }
 }
 
-int g_num_cus = 0;
 
 template <int DT, int CIN, int COUT>
 int launch(const ConvParams& p, hipStream_t stream) {
     constexpr int LDS_BYTES = IN_LDS_BYTES + 2 * COUT * W_ROW_PITCH;
     { const int rc_lds = hrn_allow_lds((const void*)conv3x3_kernel<DT, CIN, COUT>, LDS_BYTES); if (rc_lds) return rc_lds; }
-    if (g_num_cus == 0) {
-        int dev = 0, n = 0;
-        HRN_HIP(hipGetDevice(&dev));
-        HRN_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        g_num_cus = n > 0 ? n : 256;
-    }
     const long tiles = (long)((p.W + CONV_TILE_W - 1) / CONV_TILE_W) * ((p.H + CONV_TILE_H - 1) / CONV_TILE_H);
     const long total = tiles * p.M;
     HRN_CHECK(total > 0 && total < (1L << 40), -2, "conv3x3: bad tile count %ld", total);
-    long grid = (2L / (COUT / 64)) * g_num_cus;     // one persistent round: 8 waves per CU (2 x 256 or 1 x 512 threads)
+    long grid = (2L / (COUT / 64)) * hrn_device_cus();     // one persistent round: 8 waves per CU (2 x 256 or 1 x 512 threads)
     if (total < grid) grid = total;
     if (grid >= 8) grid &= ~7L;             // windows split evenly over the 8 XCDs
     static const char* fam_names[2][2][2] = {{{"conv3x3_f32_64x64", "conv3x3_f32_64x128"}, {"conv3x3_f32_128x64", "conv3x3_f32_128x128"}},

@@ -407,7 +407,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
     }
 }
 
-int g_r64_cus = 0;
 
 template <bool RES>
 int launch_r64(const ConvParams& p, long grid, hipStream_t stream) {
@@ -423,17 +422,11 @@ int launch_r64(const ConvParams& p, long grid, hipStream_t stream) {
 int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream) {
     if (p.scale || p.relu || p.in_pair || p.res_mode == 2) return -100;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    if (g_r64_cus == 0) {
-        int dev = 0, n = 0;
-        HRN_HIP(hipGetDevice(&dev));
-        HRN_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        g_r64_cus = n > 0 ? n : 256;
-    }
     const long tiles = (long)((p.W + CONV_TILE_W - 1) / CONV_TILE_W) * ((p.H + CONV_TILE_H - 1) / CONV_TILE_H);
     const long total = tiles * p.M;
     HRN_CHECK(total > 0, -2, "conv3x3_r64: bad tile count %ld", total);
     if (total >= (1L << 30) || (long)p.H * p.W * 128 >= (1L << 31)) return -100;     // 32-bit tile / in-image byte arithmetic
-    long grid = g_r64_cus;
+    long grid = hrn_device_cus();
     if (total < grid) grid = total;
     if (grid >= 8) grid &= ~7L;
     const double px = (double)p.M * p.H * p.W;

@@ -470,23 +470,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v3_kernel(const ConvParams p) 
     if constexpr (OFFLOAD) lds_done_then_barrier();         // final barrier: hands the last staging tile to the INPUT waves
 }
 
-int g_v3_cus = 0;
 
 template <int CIN, int COUT, bool OFFLOAD>
 int launch_v3(const ConvParams& p, hipStream_t stream) {
     constexpr int LDS_BYTES = V3Geom<COUT, OFFLOAD>::LDS_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     { const int rc_lds = hrn_allow_lds((const void*)conv3x3_v3_kernel<CIN, COUT, OFFLOAD>, LDS_BYTES); if (rc_lds) return rc_lds; }
-    if (g_v3_cus == 0) {
-        int dev = 0, n = 0;
-        HRN_HIP(hipGetDevice(&dev));
-        HRN_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        g_v3_cus = n > 0 ? n : 256;
-    }
     const long tiles = (long)((p.W + CONV_TILE_W - 1) / CONV_TILE_W) * ((p.H + CONV_TILE_H - 1) / CONV_TILE_H);
     const long total = tiles * p.M;
     HRN_CHECK(total > 0 && total < (1L << 40), -2, "conv3x3_v3: bad tile count %ld", total);
-    long grid = g_v3_cus;                   // one persistent 8-wave workgroup per CU
+    long grid = hrn_device_cus();                   // one persistent 8-wave workgroup per CU
     if (total < grid) grid = total;
     if (grid >= 8) grid &= ~7L;
     static const char* fam = CIN == 64 ? "conv3x3_bf16_64x64" : (COUT == 64 ? "conv3x3_bf16_128x64" : "conv3x3_bf16_128x128");
@@ -528,21 +521,7 @@ int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t st
         if (v6 < 0) { const char* e = getenv("HRN_CONV_V6"); v6 = e ? atoi(e) : 1; }
         if (v6) { const int rc = hrn_launch_conv3x3_v6(cout, p, stream); if (rc != -100) return rc; }
     }
-    if (cin == 128 && cout == 128) {
-        // the same structure on v_mfma_f32_16x16x32_bf16 (conv3x3_v5.hip).  HRN_CONV_V5 = 0: off, 1 (default): layers without a
-        // residual, 2: with the pair-gather residual too (ties v4 there)
-        static int v5 = -1;
-        if (v5 < 0) { const char* e = getenv("HRN_CONV_V5"); v5 = e ? atoi(e) : 1; }
-        if (v5 >= (p.res_mode ? 2 : 1)) { const int rc = hrn_launch_conv3x3_v5(p, stream); if (rc != -100) return rc; }
-    }
-    if (cin == 128) {
-        // 512-pixel-tile, 8-MFMA-wave, LDS-DMA kernel (conv3x3_v4.hip) for the fusion level's three layers;
-        // HRN_CONV_V4 = 0: off, 1: 128 -> 128 only, 2 (default): 128 -> 64 as well (0.56 ms per launch at c3 against 0.58 on v3
-        // since the hand-issued fragment reads and the staggered DMA issue)
-        static int v4 = -1;
-        if (v4 < 0) { const char* e = getenv("HRN_CONV_V4"); v4 = e ? atoi(e) : 2; }
-        if (v4 >= (cout == 64 ? 2 : 1)) { const int rc = hrn_launch_conv3x3_v4(cout, p, stream); if (rc != -100) return rc; }
-    }
+    // what conv3x3_r64 / v6 / v7 decline (images beyond their 32-bit in-image offsets, > 8.3 Mpixel) runs on this file's kernel
     if (cin == 128 && cout == 64) return offload ? launch_v3<128, 64, true>(p, stream) : launch_v3<128, 64, false>(p, stream);
     if (cin == 128 && cout == 128)
         return (offload && p.res_mode == 0) ? launch_v3<128, 128, true>(p, stream) : launch_v3<128, 128, false>(p, stream);

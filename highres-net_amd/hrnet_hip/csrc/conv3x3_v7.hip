@@ -9,7 +9,7 @@
 // cycles), which leaves the port half idle.
 //   per wave   pixel rows 2w, 2w+1 (two blocks of 32 pixels) x COUT output channels (COUT / 32 blocks): COUT accumulator
 //              registers; a k-step (16 input channels of one tap) = NCB A + 2 B fragment reads for 2 NCB MFMAs, reads of step
-//              i+1 issued one per MFMA gap of step i (hand-written ds_read_b128, counted lgkmcnt: conv3x3_v4.hip)
+//              i+1 issued one per MFMA gap of step i (hand-written ds_read_b128 with counted lgkmcnt, see conv3x3_v6.hip)
 //   LDS images rows of 64 bytes (32 input channels) per cout / halo pixel, 16-byte chunk c stored at c ^ ((row >> 2) & 3)
 //              (conflict-free ds_read_b128); applied on the DMA source side and on the read
 //   B address  one register per (halo row 2w + j, tap column kx); k-step 1 is the same address with bit 5 flipped (one v_xor)
@@ -454,8 +454,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v7_kernel(const ConvParams p) 
     wait_vm7<0>();                                          // nothing of this workgroup may still be in flight when it ends
 }
 
-int g_v7_cus[16];
-
 template <int COUT, int RESM, bool PAIR>
 int launch_v7(const ConvParams& p, long grid, hipStream_t stream) {
     typedef G7<COUT> GEO;
@@ -477,19 +475,11 @@ int hrn_launch_conv3x3_v7(int cout, const ConvParams& p, hipStream_t stream) {
     if (cout == 64 && ((p.res_mode != 0 && p.res_mode != 3) || p.in_pair)) return -100;
     if ((p.in_pair || p.res_mode == 2) && p.pair_h <= 0) return -100;
     if (p.res_mode == 3 && (p.out_h <= 0 || !p.res)) return -100;
-    int dev = 0;
-    HRN_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return -100;
-    if (g_v7_cus[dev] == 0) {
-        int n = 0;
-        HRN_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        g_v7_cus[dev] = n > 0 ? n : 256;
-    }
     const long tiles = (long)((p.W + T7_W - 1) / T7_W) * ((p.H + T7_H - 1) / T7_H);
     const long total = tiles * p.M;
     HRN_CHECK(total > 0, -2, "conv3x3_v7: bad tile count %ld", total);
     if (total >= (1L << 30) || (long)p.H * p.W * 256 >= (1L << 31)) return -100;     // 32-bit tile / in-image byte arithmetic
-    long grid = g_v7_cus[dev];
+    long grid = hrn_device_cus();
     if (total < grid) grid = total;
     if (grid >= 8) grid &= ~7L;
     const double px = (double)p.M * p.H * p.W;

@@ -94,3 +94,17 @@ int hrn_allow_lds(const void* kernel, int bytes) {
     done.insert({dev, kernel});
     return 0;
 }
+
+// ---- compute units of the CURRENT device (persistent kernels launch one workgroup per CU): cached per device, thread-safe
+int hrn_device_cus(void) {
+    static std::mutex mu;
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}

@@ -269,15 +269,7 @@ struct SnTrainWs {
     size_t ga, gb, xr, dxr, dz1, sums, wt, wtp, zero_bias, dxin, gmeans, scratch;
     size_t total;
 };
-int sn_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, c = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) n = c;
-        else n = 256;
-    }
-    return n;
-}
+int sn_cus() { return hrn_device_cus(); }
 SnTrainWs sn_train_ws(int B) {
     SnTrainWs w;
     memset(&w, 0, sizeof w);
@@ -362,7 +354,7 @@ int hrn_shiftnet_forward_train(const void* packed, const hrn_shiftnet_params* P,
 int hrn_shiftnet_backward(const hrn_shiftnet_params* P, const float* x, int B, const unsigned char* dropout_mask, const float* d_theta,
                           const hrn_shiftnet_params* G, float* d_x, void* tws, size_t tws_bytes, void* stream) {
     HRN_CHECK(P && G && x && d_theta && tws, -2, "hrn_shiftnet_backward: null argument");
-    HRN_CHECK(B > 0 && B <= 32, -2, "hrn_shiftnet_backward: batch %d outside 1..32", B);
+    HRN_CHECK(B > 0, -2, "hrn_shiftnet_backward: empty batch");
     const SnTrainWs T = sn_train_ws(B);
     HRN_CHECK(tws_bytes >= T.total, -3, "hrn_shiftnet_backward: workspace too small (%zu < %zu)", tws_bytes, T.total);
     hipStream_t s = (hipStream_t)stream;
@@ -383,7 +375,9 @@ int hrn_shiftnet_backward(const hrn_shiftnet_params* P, const float* x, int B, c
     const size_t nflat = (size_t)B * FCK;
     hipLaunchKernelGGL(fc_to_ref_kernel, dim3(ew_grid(nflat)), dim3(256), 0, s, (const float*)at(tws, T.ypost[7]), dropout_mask, xr, nflat);
     hipLaunchKernelGGL(fc1_bwd_w_kernel, dim3(FCK / 256, 1024), dim3(256), 0, s, (const float*)dz1, (const float*)xr, mut(G->fc1_w), B);
-    hipLaunchKernelGGL(fc1_bwd_x_kernel, dim3(FCK / 256), dim3(256), 0, s, (const float*)dz1, P->fc1_w, dxr, B);
+    for (int b0 = 0; b0 < B; b0 += 32)      // the kernel keeps 32 samples' partial sums in registers: larger batches go in groups
+        hipLaunchKernelGGL(fc1_bwd_x_kernel, dim3(FCK / 256), dim3(256), 0, s, (const float*)dz1 + (size_t)b0 * 1024, P->fc1_w,
+                           dxr + (size_t)b0 * FCK, B - b0 < 32 ? B - b0 : 32);
     hipLaunchKernelGGL(fc_from_ref_kernel, dim3(ew_grid(nflat)), dim3(256), 0, s, (const float*)dxr, dropout_mask, cur, nflat);
     HRN_LAUNCH_CHECK();
     // ---- layers 8 .. 1                                                                        ShiftNet.py:16-41, :59-67

@@ -112,6 +112,67 @@ def allreduce_gradients(modules, bucket_mb=64):
     return total
 
 
+class GradBuckets:
+    """Overlapped averaging of ONE flat gradient buffer over the ranks (the exchange step of a data-parallel train step,
+    SURVEY.md sections 5 and 8e).
+
+    `params` are the parameters whose `.grad` are consecutive views of `flat` (the layout hrnet_hip.optim.FusedAdam builds);
+    `early` is a contiguous run of them whose gradients autograd finishes FIRST - for `src/train.py` that is ShiftNet
+    (`loss -> lanczos -> ShiftNet -> HRNet`): its 137 MB, 98 % of the message, are complete while the whole backward pass of HRNet
+    is still to run.  A post-accumulate hook on every early parameter counts them in; the last one puts the early slice on the
+    wire (`all_reduce(..., async_op=True)`: RCCL works on its own stream behind the kernels already queued), and `finish()`,
+    called between `loss.backward()` and `optimizer.step()`, reduces what is left (HRNet: 2.4 MB), waits, and divides by the
+    world size.  Without a process group everything is the identity.  Works on any device (the CPU tests drive it on gloo)."""
+
+    def __init__(self, flat, params, early=()):
+        self.flat, self.params = flat, list(params)
+        early = list(early)
+        ids = {id(p): i for i, p in enumerate(self.params)}
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += p.numel()
+        self.n = off
+        self.lo = self.hi = 0
+        self._early_n = len(early)
+        if early:
+            idx = sorted(ids[id(p)] for p in early)
+            if idx != list(range(idx[0], idx[0] + len(idx))):
+                raise ValueError("GradBuckets: the early parameters must be consecutive in the flat buffer")
+            self.lo, self.hi = offs[idx[0]], offs[idx[-1]] + self.params[idx[-1]].numel()
+            for p in early:
+                p.register_post_accumulate_grad_hook(self._arrived)
+        self._count, self._work, self.early_launched_in_backward = 0, [], False
+
+    def begin(self):
+        """Start of a step (optimizer.zero_grad()): forget the previous step's counts."""
+        self._count, self._work, self.early_launched_in_backward = 0, [], False
+
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def _arrived(self, _param):
+        self._count += 1
+        if self._count == self._early_n and self._active():
+            self._work.append(dist.all_reduce(self.flat[self.lo:self.hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.early_launched_in_backward = True
+
+    def finish(self):
+        """After backward: reduce the rest, wait for everything, average.  Returns the bytes this rank put on the wire."""
+        if not self._active():
+            return 0
+        if self._early_n and not self.early_launched_in_backward:          # e.g. a parameter that took no part in this step
+            self._work.append(dist.all_reduce(self.flat[self.lo:self.hi], op=dist.ReduceOp.SUM, async_op=True))
+        for a, b in ((0, self.lo), (self.hi, self.n)):
+            if b > a:
+                self._work.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        for w in self._work:
+            w.wait()
+        self._work = []
+        self.flat[:self.n].div_(dist.get_world_size())
+        return self.n * self.flat.element_size()
+
+
 def finalize():
     if dist.is_initialized():
         dist.destroy_process_group()

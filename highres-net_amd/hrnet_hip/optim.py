@@ -7,20 +7,24 @@ Drop-in for the reference's `optim.Adam(list(fusion_model.parameters()) + list(r
 What is different underneath: every parameter of a group is re-homed into ONE flat fp32 device buffer (the parameters
 become views of it), their gradients live in one flat buffer as well (`p.grad` are views), and `step()` is a single
 `hrn_adam_step` launch per group instead of ~10 framework kernels per tensor.  The flat gradient buffer is also what
-the data-parallel exchange reduces: `allreduce()` issues one all-reduce per group (139 MB for the two models - on xGMI a
-few large messages beat many small ones), between `loss.backward()` and `step()`.
+the data-parallel exchange reduces (`allreduce()`, between `loss.backward()` and `step()`): with `overlap_early=regis_model.parameters()`
+ShiftNet's 137 MB slice goes on the wire from a backward hook as soon as `hrn_shiftnet_backward` has written it, under the whole
+HRNet backward pass; `allreduce()` then reduces HRNet's 2.4 MB and waits (hrnet_hip.dist.GradBuckets).
 """
 import torch
-import torch.distributed as dist
 
 from . import binding
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, overlap_early=None):
+        """overlap_early: parameters (consecutive in `params`, e.g. `regis_model.parameters()`) whose gradients autograd completes
+        first: their slice of the flat gradient buffer is all-reduced from a backward hook while the rest of the backward pass
+        still runs (hrnet_hip.dist.GradBuckets); `allreduce()` then only has the remainder left."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        early_ids = {id(p) for p in (overlap_early or [])}
         self._flat = []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
@@ -43,7 +47,9 @@ class FusedAdam(torch.optim.Optimizer):
                     p.data = flat_p[off:off + k].view(p.shape)          # the parameter now lives in the flat buffer
                     p.grad = flat_g[off:off + k].view(p.shape)
                     off += k
-            self._flat.append(dict(params=ps, p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), step=0))
+            from .dist import GradBuckets
+            buckets = GradBuckets(flat_g, ps, [p for p in ps if id(p) in early_ids])
+            self._flat.append(dict(params=ps, p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), step=0, buckets=buckets))
         binding.bump_param_epoch()
 
     def zero_grad(self, set_to_none=False):
@@ -53,6 +59,7 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             f["g"].zero_()
             self._rebind(f)
+            f["buckets"].begin()
 
     @staticmethod
     def _rebind(f):
@@ -67,21 +74,51 @@ class FusedAdam(torch.optim.Optimizer):
             off += k
 
     def allreduce(self):
-        """Average the flat gradient buffers over the process group (identity without one).  Returns bytes reduced."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
-            return 0
+        """Average the flat gradient buffers over the process group (identity without one): waits for the slice a backward hook has
+        already put on the wire (`overlap_early`) and reduces the rest.  Call between backward() and step().  Returns bytes reduced."""
         total = 0
-        works = []
         for f in self._flat:
             if f is None:
                 continue
             self._rebind(f)
-            works.append((f, dist.all_reduce(f["g"], op=dist.ReduceOp.SUM, async_op=True)))
-            total += f["g"].numel() * 4
-        for f, w in works:
-            w.wait()
-            f["g"].div_(dist.get_world_size())
+            total += f["buckets"].finish()
         return total
+
+    # -- torch.optim.Adam's checkpoint surface: per-parameter `step`, `exp_avg`, `exp_avg_sq` (the moments live in flat buffers here)
+    def state_dict(self):
+        self.state.clear()
+        for f in self._flat:
+            if f is None:
+                continue
+            off = 0
+            for p in f["params"]:
+                k = p.numel()
+                self.state[p] = {"step": torch.tensor(float(f["step"])), "exp_avg": f["m"][off:off + k].view(p.shape).clone(),
+                                 "exp_avg_sq": f["v"][off:off + k].view(p.shape).clone()}
+                off += k
+        sd = super().state_dict()
+        self.state.clear()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)                  # param_groups (lr, betas, ...) + per-parameter state, cast to the parameters
+        for f in self._flat:
+            if f is None:
+                continue
+            off, steps = 0, set()
+            for p in f["params"]:
+                k = p.numel()
+                st = self.state.get(p)
+                if st:
+                    f["m"][off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    f["v"][off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(st["step"]))
+                off += k
+            if len(steps) > 1:
+                raise ValueError("FusedAdam keeps one step count per parameter group; the checkpoint holds several")
+            if steps:
+                f["step"] = steps.pop()
+        self.state.clear()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -96,3 +96,68 @@ def test_two_rank_gradient_allreduce(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     assert "grads averaged" in outs[0][0]
+
+
+TRAIN_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.path.join(%r, "highres-net_amd"))
+    import torch
+    from hrnet_hip import dist as hdist
+    rank, local_rank, ws = hdist.init(backend="gloo")
+    torch.manual_seed(0)                                  # identical parameters on both ranks
+    # CPU stand-ins for the two models of train.py: `fusion` (runs first in forward, LAST in backward) and `regis` (its gradients
+    # are complete first), re-homed into one flat buffer exactly as hrnet_hip.optim.FusedAdam does it
+    fusion = torch.nn.Sequential(torch.nn.Linear(64, 48), torch.nn.PReLU(), torch.nn.Linear(48, 32))
+    regis = torch.nn.Sequential(torch.nn.Linear(32, 400), torch.nn.ReLU(), torch.nn.Linear(400, 2, bias=False))
+    params = list(fusion.parameters()) + list(regis.parameters())
+    n = sum(p.numel() for p in params)
+    flat_p, flat_g = torch.zeros(n), torch.zeros(n)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            k = p.numel()
+            flat_p[off:off + k].copy_(p.reshape(-1)); p.data = flat_p[off:off + k].view(p.shape); p.grad = flat_g[off:off + k].view(p.shape)
+            off += k
+    buckets = hdist.GradBuckets(flat_g, params, early=list(regis.parameters()))
+    opt = torch.optim.SGD(params, lr=0.05)
+    seen = []
+    fusion[0].weight.register_hook(lambda g: seen.append(buckets.early_launched_in_backward))   # fires in the LAST backward node
+    for step in range(3):
+        flat_g.zero_(); buckets.begin()
+        x = torch.randn(8, 64, generator=torch.Generator().manual_seed(100 * rank + step))     # every rank its own shard
+        loss = (regis(fusion(x)) ** 2).mean()
+        loss.backward()
+        local = flat_g.clone()
+        nbytes = buckets.finish()
+        assert nbytes == n * 4
+        both = [torch.zeros_like(local) for _ in range(ws)]
+        torch.distributed.all_gather(both, local)
+        assert torch.allclose(flat_g, sum(both) / ws, rtol=1e-6, atol=1e-8)
+        opt.step()
+    assert seen == [True] * 3, seen                        # the early slice was on the wire before fusion's backward finished
+    mine = flat_p.clone()
+    both = [torch.zeros_like(mine) for _ in range(ws)]
+    torch.distributed.all_gather(both, mine)
+    assert torch.equal(both[0], both[1])                   # rank-identical parameters after the steps
+    hdist.barrier()
+    if rank == 0:
+        print("train loop ok")
+    hdist.finalize()
+""") % ROOT
+
+
+def test_two_rank_train_loop_with_overlapped_exchange(tmp_path):
+    """BASELINE configs[3] (data-parallel `src/train.py` loop) on CPU stand-ins: the early bucket (the registration model's
+    gradients) is all-reduced from a backward hook while the fusion model's backward still runs, the rest after backward; the
+    averaged gradients equal the hand-gathered mean and both ranks hold identical parameters after three optimiser steps."""
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    assert "train loop ok" in outs[0][0]

@@ -27,12 +27,19 @@ def _fresh_model(alpha_residual=True, seed=1234):
 
 def _oracle_grads(lrs, alphas, cot, alpha_residual, seed=1234):
     st = {k: v.double().requires_grad_(True) for k, v in weights.to_torch_state(weights.hrnet_state(seed)).items()}
-    with torch.enable_grad():
-        sr = torch_port.hrnet_forward.__wrapped__(torch.from_numpy(lrs).double(), torch.from_numpy(alphas).double(), st,
-                                                  num_layers=weights.HRNET_CONFIG["encoder"]["num_layers"], alpha_residual=alpha_residual)
-        (sr * torch.from_numpy(cot).double()).sum().backward()
+    abs_terms = {}
+    torch_port.ABS_TERMS = abs_terms             # sum |terms| of every single-slope / final-bias gradient (oracle/torch_port.py)
+    try:
+        with torch.enable_grad():
+            sr = torch_port.hrnet_forward.__wrapped__(torch.from_numpy(lrs).double(), torch.from_numpy(alphas).double(), st,
+                                                      num_layers=weights.HRNET_CONFIG["encoder"]["num_layers"], alpha_residual=alpha_residual)
+            (sr * torch.from_numpy(cot).double()).sum().backward()
+    finally:
+        torch_port.ABS_TERMS = None
     # parameters the graph never touched (the fusion block when V == 1) have no gradient in torch: zero here
-    return sr.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in st.items()}
+    grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in st.items()}
+    grads["__abs_terms__"] = abs_terms
+    return sr.detach().numpy(), grads
 
 
 @pytest.mark.parametrize("B,V,S,n_real,alpha_residual", [
@@ -52,15 +59,17 @@ def test_hrnet_backward_vs_autograd_oracle(B, V, S, n_real, alpha_residual):
     assert sr.requires_grad
     assert util.rel_err(sr.detach().cpu().numpy(), want_sr) <= 2e-5
     (sr * util.dev(cot)).sum().backward()
-    # PReLU-slope / scalar gradients are sums of ~1e4..1e5 signed terms that can cancel to a small net value (the stem's at
-    # V = 1: 0.026 against 12..37 for the other slopes; CPU fp32 autograd is itself 2e-4 off the fp64 value there), so
-    # scalars are held to 2e-4 of the LARGEST scalar gradient of the model, tensors to 2e-4 of their own max-norm.
-    scalar_scale = max(float(np.abs(want[k]).max()) for k, p in m.named_parameters() if p.numel() == 1)
+    # PReLU-slope / final-bias gradients are sums of ~1e4..1e5 signed terms that can cancel to a small net value (the stem's at
+    # V = 1: 0.026 against a sum of |terms| in the tens).  A float32 implementation carries each TERM to ~1e-6..1e-5 relative, so
+    # its error on the sum is bounded by that times sum |terms| - which the oracle records (torch_port.ABS_TERMS); scalars are
+    # held to 2e-5 of sum |terms| of their own defining sum, tensors to 2e-4 of their own max-norm.
+    abs_terms = want["__abs_terms__"]
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         got = p.grad.cpu().numpy()
         if p.numel() == 1:
-            assert abs(float(got.ravel()[0]) - float(want[k].ravel()[0])) <= 2e-4 * scalar_scale, (k, got, want[k])
+            bound = 2e-5 * abs_terms.get(k, 0.0) + 1e-12
+            assert abs(float(got.ravel()[0]) - float(want[k].ravel()[0])) <= bound, (k, got, want[k], abs_terms.get(k))
         else:
             e = util.rel_err(got, want[k])
             assert e <= 2e-4, (k, e)
@@ -69,6 +78,62 @@ def test_hrnet_backward_vs_autograd_oracle(B, V, S, n_real, alpha_residual):
     (sr2 * util.dev(cot)).sum().backward()
     k0, p0 = next(iter(m.named_parameters()))
     assert util.rel_err(p0.grad.cpu().numpy(), 2 * want[k0]) <= 2e-4
+
+
+def test_backward_twice_with_retain_graph():
+    """`loss.backward(retain_graph=True)` followed by a second backward through the same graph: the workspaces of the HIP
+    forward-for-training stay intact (nothing in the backward kernels writes into them) and the gradients accumulate to twice
+    the single-pass values, for HRNet and for ShiftNet."""
+    from DeepNetworks.ShiftNet import ShiftNet
+    lrs, alphas, _ = synth.make_batch(5, 2, 4, 16, 4)
+    m = _fresh_model()
+    out = (m(util.dev(lrs), util.dev(alphas)) ** 2).sum()
+    out.backward(retain_graph=True)
+    once = {k: p.grad.clone() for k, p in m.named_parameters()}
+    out.backward()
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * once[k], rtol=1e-5, atol=1e-6 * float(once[k].abs().max()) + 1e-12), k
+    sn = ShiftNet()
+    sn.load_state_dict(weights.to_torch_state(weights.shiftnet_state(4321)))
+    sn = sn.cuda().train()
+    x = torch.rand(3, 2, 128, 128, device="cuda").requires_grad_(True)
+    th = (sn(x) ** 2).sum()
+    th.backward(retain_graph=True)
+    gx = x.grad.clone()
+    th.backward()
+    assert torch.allclose(x.grad, 2 * gx, rtol=1e-5, atol=1e-6 * float(gx.abs().max()) + 1e-12)
+
+
+def test_predict_py_path_hits_the_asked_precision():
+    """src/predict.py never calls .eval() and uses no no_grad (load_model :86-100, get_sr_and_score :17-49): re-enact it on a FRESH
+    module.  precision fp32: same numbers as the .eval() forward; precision bf16: the bf16 inference kernels run (bit-identical
+    to .eval()), not the fp32 training kernels - and a backward pass through that result still works (recomputed in fp32)."""
+    from DeepNetworks.HRNet import HRNet
+    lrs, alphas, hrs = synth.make_batch(17, 1, 9, 32, 7)                 # one imageset, as get_sr_and_score collates it
+    x, a = util.dev(lrs), util.dev(alphas)
+    for prec in ("fp32", "bf16"):
+        cfg = {k: dict(v) for k, v in weights.HRNET_CONFIG.items()}
+        cfg["precision"] = prec
+        model = HRNet(cfg).cuda()                                        # load_model: no .eval()
+        model.load_state_dict(weights.to_torch_state(weights.hrnet_state(1234)))
+        assert model.training
+        sr = model(x, a)[:, 0]                                           # predict.py:39
+        got = sr.detach().cpu().numpy()[0]                               # :40
+        with torch.no_grad():
+            want = model.eval()(x, a)[:, 0].cpu().numpy()[0]
+        if prec == "bf16":
+            assert np.array_equal(got, want)
+        else:
+            assert util.rel_err(got, want) <= 1e-6
+        model.train()
+        sr2 = model(x, a)
+        (sr2 ** 2).sum().backward()
+        ref_m = _fresh_model()
+        (ref_m(x, a) ** 2).sum().backward()
+        g1 = dict(model.named_parameters())["fuse.fuse.1.weight"].grad
+        g0 = dict(ref_m.named_parameters())["fuse.fuse.1.weight"].grad
+        tol = 1e-5 if prec == "fp32" else 5e-2           # bf16: d(sr^2) is taken at the bf16-rounded output, the chain itself is fp32
+        assert float((g1 - g0).abs().max()) <= tol * float(g0.abs().max()), prec
 
 
 def test_hrnet_train_step_reduces_loss():
@@ -134,9 +199,9 @@ def test_lanczos_shift_backward_vs_autograd(b, c, H, W):
 _torch_shiftnet = torch_port.shiftnet_forward_train   # ShiftNet.forward in train mode with a given dropout keep-mask (same pin)
 
 
-def test_shiftnet_backward_vs_autograd():
+@pytest.mark.parametrize("B", [3, 35])          # 35: more pairs than one fc1 data-gradient launch holds (groups of 32)
+def test_shiftnet_backward_vs_autograd(B):
     from DeepNetworks.ShiftNet import ShiftNet
-    B = 3
     rng = np.random.Generator(np.random.PCG64(21))
     x = (rng.random((B, 2, 128, 128), dtype=np.float32) * 0.25).astype(np.float32)
     x[:, 1] = 0.7 * x[:, 0] + 0.3 * x[:, 1]                  # correlated pair, like (reference, image)
@@ -164,7 +229,13 @@ def test_shiftnet_backward_vs_autograd():
     assert theta.requires_grad
     assert util.rel_err(theta.detach().cpu().numpy(), want.detach().numpy()) <= 2e-4
     (theta * util.dev(cot)).sum().backward()
-    assert util.rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) <= 2e-3
+    # the input gradient: ReLU and max-pool are discontinuous in their derivative, so a pre-activation that is +1e-9 in fp64 and
+    # -1e-9 in fp32 (or a pool window whose two largest values swap) moves single elements by O(1 %) of the largest gradient: with
+    # more samples such events become certain (measured: per sample either ~1e-5 or ~1e-2 at B = 16..35, B <= 32 included).  All
+    # but 0.5 % of the elements (one flipped unit of a deep layer reaches a large input patch; 0.10 % measured at B = 35) must agree
+    # to 2e-3, and none may be off by more than 5e-2.
+    err = np.abs(gx.grad.cpu().numpy() - tx.grad.numpy()) / np.abs(tx.grad.numpy()).max()
+    assert err.max() <= (2e-3 if B <= 4 else 5e-2) and float((err > 2e-3).mean()) <= 5e-3, (err.max(), float((err > 2e-3).mean()))
     for k, p in m.named_parameters():
         got, ref = p.grad.cpu().numpy(), st[k].grad.numpy()
         if k.endswith(".0.bias"):

@@ -91,14 +91,14 @@ def test_conv_pack_index_math(cin, cout, es):
 
 def test_stamp_instrumenters_still_apply(tmp_path):
     """tools/stamps/instr_*.py patch s_memtime stamps into copies of the conv kernels by text anchors (profiles/
-    r01_final_inkernel_stamps.txt was made with them): every anchor must still exist in the current sources."""
+    r01_final_inkernel_stamps.txt was made with them; conv3x3_v6 carries its stamps itself, -DV6_STAMP): every anchor must still
+    exist in the current sources."""
     import shutil
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "highres-net_amd", "hrnet_hip", "csrc")
-    for which, fn, marker in (("r64", "conv3x3_r64.hip", "hrn_dbg_read_stamps"), ("v4", "conv3x3_v4.hip", "hrn_dbg_read_stamps_v4"),
-                              ("v5", "conv3x3_v5.hip", "hrn_dbg_read_stamps_v5")):
+    for which, fn, marker in (("r64", "conv3x3_r64.hip", "hrn_dbg_read_stamps"),):
         d = tmp_path / which
         d.mkdir()
         shutil.copy(os.path.join(csrc, fn), d / fn)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# build.sh <name> [r64|v4]: copy csrc/ to scratch/x/<name>, instrument one kernel, link scratch/x/<name>/lib.so
-# then on the GPU:  HRNET_HIP_LIB=scratch/x/<name>/lib.so python tools/stamps/read_r64.py   (or read_v4.py)
+# build.sh <name> r64: copy csrc/ to scratch/x/<name>, instrument one kernel, link scratch/x/<name>/lib.so
+# then on the GPU:  HRNET_HIP_LIB=scratch/x/<name>/lib.so python tools/stamps/read_r64.py   (conv3x3_v6: -DV6_STAMP + tools/stamps/read_v6.py)
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 D=$ROOT/scratch/x/$1
