@@ -174,7 +174,7 @@ class HRNet(nn.Module):
             fn = _HRNetLazyTrainFunction if self._dtype() == binding.BF16 else _HRNetTrainFunction
             return fn.apply(self, names, lrs.detach(), alphas.detach(), *[p for _, p in self.named_parameters()])
         packed, dt = self.packed_parameters()
-        return binding.hrnet_forward(packed, dt, self._num_layers, self.fuse.alpha_residual, lrs.detach(), alphas.detach())
+        return torch.ops.hrnet_hip.hrnet_forward(packed, dt, self._num_layers, bool(self.fuse.alpha_residual), lrs.detach(), alphas.detach())
 
     def _packed_f32(self):
         named = dict(self.named_parameters())

@@ -557,3 +557,49 @@ def shift_cpsnr(srs, hrs, hr_maps, border_w=3, clip=True):
         _check(lib.hrn_shift_cpsnr(_ptr(srs.contiguous()), _ptr(hrs.contiguous()), _ptr(hr_maps.contiguous()), B, S, int(border_w),
                                    int(bool(clip)), _ptr(out), _ptr(ws), ws.numel(), _stream()), "hrn_shift_cpsnr")
     return out
+
+
+# --------------------------------------------------------------------------- PyTorch-ROCm custom ops (north_star: "exposed to Python as
+# PyTorch-ROCm custom ops"): the inference entry points are registered with the dispatcher as torch.ops.hrnet_hip.*, with fake
+# (meta) implementations, so that they are visible to torch.compile / export and to anyone calling through torch.ops.  Each is a
+# thin shim over the ctypes call above - the C ABI stays the boundary.  The reference-named modules call THESE in eval mode.
+@torch.library.custom_op("hrnet_hip::hrnet_forward", mutates_args=(), device_types="cuda")
+def _op_hrnet_forward(packed: torch.Tensor, dtype: int, num_layers: int, alpha_residual: bool, lrs: torch.Tensor,
+                      alphas: torch.Tensor) -> torch.Tensor:
+    return hrnet_forward(packed, dtype, num_layers, alpha_residual, lrs, alphas)
+
+
+@_op_hrnet_forward.register_fake
+def _(packed, dtype, num_layers, alpha_residual, lrs, alphas):
+    b, _, h, w = lrs.shape
+    return lrs.new_empty((b, 1, 3 * h, 3 * w), dtype=torch.float32)
+
+
+@torch.library.custom_op("hrnet_hip::lanczos_shift", mutates_args=(), device_types="cuda")
+def _op_lanczos_shift(img: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    return lanczos_shift(img, shift)
+
+
+@_op_lanczos_shift.register_fake
+def _(img, shift):
+    return img.new_empty(img.shape, dtype=torch.float32)
+
+
+@torch.library.custom_op("hrnet_hip::lanczos_kernel", mutates_args=(), device_types="cuda")
+def _op_lanczos_kernel(dx: torch.Tensor) -> torch.Tensor:
+    return lanczos_kernel(dx)
+
+
+@_op_lanczos_kernel.register_fake
+def _(dx):
+    return dx.new_empty((dx.numel(), 7), dtype=torch.float32)
+
+
+@torch.library.custom_op("hrnet_hip::shift_cpsnr", mutates_args=(), device_types="cuda")
+def _op_shift_cpsnr(srs: torch.Tensor, hrs: torch.Tensor, hr_maps: torch.Tensor, border_w: int, clip: bool) -> torch.Tensor:
+    return shift_cpsnr(srs, hrs, hr_maps, border_w, clip)
+
+
+@_op_shift_cpsnr.register_fake
+def _(srs, hrs, hr_maps, border_w, clip):
+    return srs.new_empty((srs.shape[0] if srs.dim() == 3 else 1,), dtype=torch.float32)

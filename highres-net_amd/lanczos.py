@@ -33,7 +33,7 @@ def lanczos_shift(img, shift, p=3, a=3, N=7):
     if torch.is_grad_enabled() and ((torch.is_tensor(img) and img.requires_grad) or (torch.is_tensor(shift) and shift.requires_grad)):
         out = _LanczosShiftFunction.apply(img, shift)          # differentiable wrt the image and the shifts (apply_shifts)
     else:
-        out = binding.lanczos_shift(img, shift)
+        out = torch.ops.hrnet_hip.lanczos_shift(img, shift) if img.is_cuda and shift.is_cuda else binding.lanczos_shift(img, shift)
     return out if img.dtype == torch.float32 else out.to(img.dtype)
 
 

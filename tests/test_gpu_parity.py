@@ -303,6 +303,24 @@ def test_bf16_kernels_on_awkward_sizes_vs_fp32_path(S, V):
     assert util.rel_err(got, ref) <= 4e-2 and util.psnr_db(got, ref) >= 42.0
 
 
+def test_entry_points_are_registered_torch_ops():
+    """north_star: "exposed to Python as PyTorch-ROCm custom ops".  The inference entry points are dispatcher-registered
+    (torch.ops.hrnet_hip.*) with fake implementations: callable through torch.ops, shape-inferable on the meta device, and the
+    eval-mode module goes through them."""
+    from hrnet_hip import binding
+    lrs, alphas = synth.fast_batch(5, 2, 4, 32)
+    m = util.hip_hrnet("fp32")
+    packed, dt = m.packed_parameters()
+    x, a = util.dev(lrs), util.dev(alphas)
+    with torch.no_grad():
+        via_ops = torch.ops.hrnet_hip.hrnet_forward(packed, dt, 2, True, x, a)
+        assert torch.equal(via_ops, m(x, a))
+        img = torch.rand(1, 3, 40, 40, device="cuda")
+        sh = torch.tensor([[0.3, -0.2], [0.0, 0.0], [1.5, 0.25]], device="cuda")
+        assert torch.equal(torch.ops.hrnet_hip.lanczos_shift(img, sh), binding.lanczos_shift(img, sh))
+    assert torch.library.opcheck(torch.ops.hrnet_hip.lanczos_shift.default, (img, sh), test_utils=("test_schema", "test_faketensor")) is not None
+
+
 def test_forward_is_graph_capturable():
     """The C ABI promises that calls only enqueue work (no allocation, no synchronisation, no host read-back; include/hrnet_hip.h):
     capture HRNet.forward (bf16, all conv kernels incl. the LDS-DMA ones) into a HIP graph and replay it on new inputs."""
