@@ -1,26 +1,34 @@
 #!/bin/bash
-# Evidence run for profiles/ (on the GPU box: gpurun -- tools/prof_all.sh): the default bench line, rocprofv3 kernel-trace stats of the
-# same command, and the two HBM traffic counter passes; results land in gpurun_out/final/ (see profiles/README.md)
+# Evidence run for profiles/ (on the GPU box: gpurun -- tools/prof_all.sh [TAG]): the default bench line, the train-mode line,
+# rocprofv3 kernel-trace stats of the same bench command, the two HBM traffic counter passes (FETCH_SIZE / WRITE_SIZE: separate
+# --pmc passes with kernel-trace only, as the MI355X guide prescribes), the MFMA-busy / clock pass and the conv3x3_v6 stamps.
+# Results land in gpurun_out/final/; tools/prof_collect.py then writes profiles/<TAG>_* from them (run here, commit).
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
-python bench.py --steps 20 --warmup 3 > $O/bench_steps20.json
+python bench.py --steps 20 --warmup 3 > $O/bench_steps20.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
 echo "bench done"
+python bench.py --mode train --steps 5 > $O/bench_train.json 2>> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
+echo "train bench done"
+python tools/kbench.py bf16 32 32 512 > $O/kbench_c5.txt 2>&1 || { tail -5 $O/kbench_c5.txt; exit 1; }
+echo "c5 done"
+if [ -f scratch/x/v6_stamp/lib.so ]; then HRNET_HIP_LIB=scratch/x/v6_stamp/lib.so python tools/stamps/read_v6.py > $O/v6_stamps.txt 2>&1 || true; fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_steps5_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_steps5_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/kbench.py bf16 > $O/pmc_fetch.out 2> $O/pmc_fetch.err || { tail -5 $O/pmc_fetch.err; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/kbench.py bf16 > $O/pmc_fetch.out 2> $O/pmc_fetch.err || { tail -5 $O/pmc_fetch.err; exit 1; }
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/kbench.py bf16 > $O/pmc_write.out 2> $O/pmc_write.err || { tail -5 $O/pmc_write.err; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/kbench.py bf16 > $O/pmc_write.out 2> $O/pmc_write.err || { tail -5 $O/pmc_write.err; exit 1; }
 echo "write done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_busy -o t -- python3 $R/tools/kbench.py bf16 > $O/pmc_busy.out 2> $O/pmc_busy.err || { tail -5 $O/pmc_busy.err; exit 1; }
+echo "busy done"
 cd $R
 for f in $(find $O/stats -name "*kernel_stats.csv"); do cp $f $O/bench_steps5_kernel_stats.csv; done
 for f in $(find $O/pmc_fetch -name "*counter_collection.csv"); do cp $f $O/pmc_fetch_counter_collection.csv; done
 for f in $(find $O/pmc_write -name "*counter_collection.csv"); do cp $f $O/pmc_write_counter_collection.csv; done
-find $O -maxdepth 3 | head -30
-ls $O
-# keep the merged-back payload small
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write
-du -sh $O
+for f in $(find $O/pmc_busy -name "*counter_collection.csv"); do cp $f $O/pmc_busy_cc.csv; done
+for f in $(find $O/pmc_busy -name "*kernel_trace.csv"); do cp $f $O/pmc_busy_kt.csv; done
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_busy
+ls $O; du -sh $O
