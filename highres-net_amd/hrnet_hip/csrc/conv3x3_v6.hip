@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
 #if V6_BAL
                 // the SIMD's arbiter prefers the older wave (w) to its partner (w + 4) all stage long: w finishes its 96 MFMAs in ~2.7 k
                 // cycles and then idles at the barrier while w + 4 runs alone at ~60 % of the pipe.  Priority for w + 4 during the first
-                // steps of the stage evens them out (stamps: profiles/r02_v6_stamps.txt)
+                // steps of the stage evens them out (stamps: profiles/r02_final_v6_stamps.txt)
                 if (w >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll

@@ -1,7 +1,7 @@
 // conv3x3 128 -> {128, 64}, bf16: the three layers of a fusion level (HRNet.py:90-97, :113-131) - 61 % of the forward FLOPs.
 // The skeleton of conv3x3_v6.hip (512-pixel tiles, 8 MFMA waves, two per SIMD, descriptor-based LDS-DMA issued from the MFMA
 // gaps, 2-slot weight ring, LDS-staged coalesced epilogue) on v_mfma_f32_32x32x16_bf16.
-// Why the other MFMA shape: the stamps of conv3x3_v6 (profiles/r02_v6_stamps.txt) show the kernel bound by the SIMD's
+// Why the other MFMA shape: the stamps of conv3x3_v6 (profiles/r02_final_v6_stamps.txt) show the kernel bound by the SIMD's
 // vector-issue port, not by the matrix pipe: an MFMA of either shape holds the port for 8 cycles, so 16x16x32 spends 8 of
 // every 16 pipe cycles on MFMA issue alone and the fragment reads, DMA issues and waits of BOTH waves of the SIMD queue up
 // behind them (a wave's 96 MFMAs of a stage took 2.7 k cycles even with priority; 1.5 k would be the pipe's rate).  With
