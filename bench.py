@@ -319,7 +319,7 @@ def main():
                 "max_rel": float((a - b).abs().max() / b.abs().max()),
                 "cpsnr_db": round(float(binding.get_loss(a[:, 0], b[:, 0], ones, "cPSNR").mean()), 2),
                 "batch": f"the timed batch (B={args.batch}, n_views={args.views})"}
-            if not args.no_extras:
+            if not args.no_extras and ws == 1:             # (multi-rank runs keep rank 0's tail short: the other ranks are already done)
                 # the exact-fp32 path at the metric's shape (the path that meets the 1e-3 contract) and BASELINE configs[1]
                 def fstep():
                     binding.hrnet_forward(p2 if other == "fp32" else packed, binding.F32, 2, True, lrs, alphas, out=sr)
