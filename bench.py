@@ -183,6 +183,8 @@ def make_train_step(device, batch, views, patch, overlap=True):
     off = (3 * patch - 128) // 2
 
     def step(exchange=True):
+        for f in opt._flat:
+            f["buckets"].enabled = exchange                                                         # also silences the backward hook
         opt.zero_grad()
         srs = fusion(lrs, alphas)                                                                   # train.py:174
         ref = hrs[:, off:off + 128, off:off + 128].reshape(-1, 1, 128, 128)
@@ -193,9 +195,13 @@ def make_train_step(device, batch, views, patch, overlap=True):
         loss = torch.mean(loss) + 1e-6 * torch.mean(shifts) ** 2                                    # :186-187
         loss.backward()                                                                             # :190
         if exchange:
+            step.early = opt._flat[0]["buckets"].early_launched_in_backward
             opt.allreduce()                                                                         # the one exchange step
         opt.step()                                                                                  # :191
         return loss
+    step.early = False
+    step.flat_parameters = opt._flat[0]["p"]                                                        # every weight of both models, one buffer
+    step.initial = opt._flat[0]["p"].clone()
     return step
 
 
@@ -223,7 +229,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {ws}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local_rank if ws > 1 else 0)
+    device = torch.device("cuda", int(os.environ.get("HRN_BENCH_DEVICE", local_rank if ws > 1 else 0)))   # override: rehearsal of N ranks on one GPU
     torch.cuda.set_device(device)
 
     if args.mode == "train":
@@ -234,14 +240,15 @@ def main():
         no_x = timed(lambda: step(exchange=False), steps, 1, device, hdist) if ws > 1 else elapsed
         if rank == 0:
             print(json.dumps({
-                "metric": "train samples/sec of the src/train.py optimisation step (B=32/GPU, n_views=32, 64x64 patches)",
+                "metric": f"train samples/sec of the src/train.py optimisation step (B={args.batch}/GPU, n_views={args.views}, {args.patch}x{args.patch} patches)",
                 "value": round(args.batch * ws * steps / elapsed, 2), "unit": "samples/s", "n_gpus": ws, "steps": steps, "warmup": warm,
                 "ms_per_step": round(elapsed / steps * 1e3, 2), "ms_per_step_without_exchange": round(no_x / steps * 1e3, 2),
+                "early_slice_launched_during_backward": bool(step.early) if ws > 1 else None,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"train.py:164-191 on the HIP modules: HRNet + ShiftNet + Lanczos + registered cPSNR loss + FusedAdam, "
                                        f"B={args.batch}/GPU, n_views={args.views}, {args.patch}x{args.patch} patches (BASELINE configs[3])",
                            "global_batch": args.batch * ws,
-                           "parallelism": f"dp{ws}: RCCL all-reduce of 139 MB of fp32 gradients per step, ShiftNet's slice overlapped with HRNet's backward",
+                           "parallelism": f"dp{ws}: {os.environ.get('HRN_DIST_BACKEND', 'RCCL')} all-reduce of 139 MB of fp32 gradients per step, ShiftNet's slice overlapped with HRNet's backward",
                            "weights": "random init (seed 1234), fc2 ~ N(0, 1e-3)"}}), flush=True)
         hdist.finalize()
         return

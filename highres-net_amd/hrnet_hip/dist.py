@@ -29,7 +29,8 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # HRN_DIST_BACKEND=gloo: rehearsal of the multi-rank paths on a box with fewer GPUs than ranks (gloo moves CUDA tensors too)
+            backend = os.environ.get("HRN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
@@ -143,13 +144,14 @@ class GradBuckets:
             for p in early:
                 p.register_post_accumulate_grad_hook(self._arrived)
         self._count, self._work, self.early_launched_in_backward = 0, [], False
+        self.enabled = True                 # False: a step without the exchange (bench.py's "without exchange" leg)
 
     def begin(self):
         """Start of a step (optimizer.zero_grad()): forget the previous step's counts."""
         self._count, self._work, self.early_launched_in_backward = 0, [], False
 
     def _active(self):
-        return dist.is_initialized() and dist.get_world_size() > 1
+        return self.enabled and dist.is_initialized() and dist.get_world_size() > 1
 
     def _arrived(self, _param):
         self._count += 1
