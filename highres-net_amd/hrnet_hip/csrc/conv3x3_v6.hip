@@ -36,7 +36,7 @@
 #include "conv3x3.h"
 
 // Timing-only ablations (tools/v6_abl.sh builds scratch/x/v6_<bits>/lib.so with -DV6_ABL=<bits>; results are WRONG when set):
-// 1 no MFMA | 2 no epilogue | 4 no DMA | 8 no output stores | 16 no residual loads | 32 no fragment reads
+// 1 no MFMA | 2 no epilogue | 4 no DMA | 8 no output stores | 16 no residual loads | 32 no fragment reads | 64 residual from one cache-resident 64 KB
 #ifndef V6_ABL
 #define V6_ABL 0
 #endif
@@ -68,13 +68,11 @@ template <int COUT> struct G6 {
     static constexpr int W_PIECES = WST / 1024;            // 24 | 12
     static constexpr int OFF_IN = 2 * WST;
     static constexpr int OFF_BIAS = OFF_IN + 2 * IN_BYTES6;
-    static constexpr int OFF_STG = OFF_BIAS + 512;
     static constexpr int ROW = COUT * 2;                   // bytes per output pixel
-    static constexpr int SEGS = ROW / 16;                  // 16-byte segments per pixel: 16 | 8
-    static constexpr int STG_WAVE = 16 * ROW;              // one round = one block of 16 pixels: 4,096 | 2,048
-    static constexpr int NPC = STG_WAVE / 1024;            // 1 KB pieces per round: 4 | 2
-    static constexpr int PPP = 1024 / ROW;                 // pixels per piece: 4 | 8
-    static constexpr int LDS_BYTES = OFF_STG + 8 * STG_WAVE;
+    static constexpr int LB = NCB * 2;                     // bytes of a pixel's row one lane holds: its NCB channels NCB*c15 .. +NCB-1
+    static constexpr int OFF_FIFO = OFF_BIAS + 512;        // 4 KB per wave: round 0 of the residual, fetched by LDS-DMA under the last stage
+    static constexpr int FIFO_WAVE = LB == 16 ? 4096 : 0;
+    static constexpr int LDS_BYTES = OFF_FIFO + 8 * FIFO_WAVE;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr6;
@@ -117,7 +115,8 @@ template <int COUT, int RESM, bool PAIR>
 __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) {
     typedef G6<COUT> GEO;
     constexpr int NCB = GEO::NCB, NQ = GEO::NQ, NSTEP = 3 * NQ, WST = GEO::WST, TAP_BYTES = GEO::TAP_BYTES;
-    constexpr int OFF_IN = GEO::OFF_IN, ROW = GEO::ROW, SEGS = GEO::SEGS, NPC = GEO::NPC, PPP = GEO::PPP;
+    constexpr int OFF_IN = GEO::OFF_IN, ROW = GEO::ROW, LB = GEO::LB;
+    typedef typename std::conditional<LB == 16, u32x4, u32x2>::type lane_row_t;       // a lane's share of one pixel's row
     constexpr bool RES = RESM != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_lds = (float*)(smem + GEO::OFF_BIAS);
@@ -183,23 +182,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
         }
     };
     // one weight piece of stage (c, tg): piece qq = (tap kx = qq / NCB, cout block jb = qq % NCB): 16 couts x 64 bytes;
-    // lane i -> cout 16 jb + (i >> 2), physical chunk i & 3 = logical (i & 3) ^ swz6(i >> 2)
+    // lane i -> row i >> 2 of the block = cout NCB * (i >> 2) + jb (the interleave that makes a lane's accumulators a contiguous
+    // piece of its pixels' rows, see the epilogue), physical chunk i & 3 = logical (i & 3) ^ swz6(i >> 2)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, 9 * 128 * COUT * 2, 0x00020000);
-    const unsigned w_lane_off = (unsigned)((lane >> 2) * 128 + (((lane & 3) ^ swz6(lane >> 2)) << 4));
+    const unsigned w_lane_off = (unsigned)((lane >> 2) * (NCB * 128) + (((lane & 3) ^ swz6(lane >> 2)) << 4));
     auto dma_w = [&](int c, int tg, int slot_, int t3) __attribute__((always_inline)) {
         const int qq = w + 8 * t3;
         if (qq < GEO::W_PIECES) {
             const int kx = qq / NCB, jb = qq - kx * NCB;
-            const unsigned soff = (unsigned)(((c >> 1) * 9 + tg * 3 + kx) * (COUT * 128) + (c & 1) * 64 + jb * 2048);
+            const unsigned soff = (unsigned)(((c >> 1) * 9 + tg * 3 + kx) * (COUT * 128) + (c & 1) * 64 + jb * 128);
             if (!(V6_ABL & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr6)(smem + slot_ * WST + kx * TAP_BYTES + jb * 1024), 16, w_lane_off, soff, 0, 0);
         }
     };
     constexpr int NW3 = (GEO::W_PIECES + 7) / 8;            // weight pieces a wave issues per stage: up to 3 | 2
     const int n_in = w < (N_IN6 & 7) ? (N_IN6 >> 3) + 1 : (N_IN6 >> 3);      // halo pieces of this wave per chunk: 5 (wave 7: 4)
 
-    const bool has_slope = p.slope != nullptr;
-    const float slope = has_slope ? p.slope[0] : 0.f;
-    const bool slope01 = slope >= 0.f && slope <= 1.f;
+    const float act_slope = p.slope ? p.slope[0] : 1.f;       // no activation == PReLU with slope 1
+    const bool slope01 = act_slope >= 0.f && act_slope <= 1.f;
 
     // fragment addresses.  A, cout block cb: a_off + slot*WST + kx*TAP + cb*1024.  B, pixel block pxb = (row
     // pxb >> 1, column half pxb & 1): halo pixel pixb[pxb] + tg*34 + kx.
@@ -251,12 +250,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
         if (nxt_t >= tiles) { nxt_t -= tiles; ++nxt_m; }
         size_t nxA = inA, nxB = inB;
         if (more_tiles) in_bases(nxt_m, nxA, nxB);
-        // accumulators start at the bias: element e of block cb = channel cb*16 + 4q + e
+        // accumulators start at the bias: every element of acc[cb][.] of this lane is channel NCB * c15 + cb
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            const f32x4 b = *(const f32x4*)(bias_lds + cb * 16 + 4 * q);
+        for (int cb4 = 0; cb4 < NCB; cb4 += 4) {
+            const f32x4 b = *(const f32x4*)(bias_lds + NCB * c15 + cb4);
 #pragma unroll
-            for (int pxb = 0; pxb < 4; ++pxb) acc[cb][pxb] = b;
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int pxb = 0; pxb < 4; ++pxb) acc[cb4 + e][pxb] = f32x4{b[e], b[e], b[e], b[e]};
         }
         // geometry of this tile's outputs (used by the residual prefetch and the epilogue)
         const int ty_ = cur_t / tiles_x;
@@ -281,29 +282,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
             }
             outp = (unsigned char*)p.out + oimg * hw * ROW;
         }
-        // residual of round r (= pixel block r of the wave): piece k, lane i <-> pixel pp = PPP*k + i / SEGS of the block and the
-        // 16-byte segment s = i % SEGS of its row.  Round 0 goes straight into the wave's staging rows by LDS-DMA during the tile's
-        // last stage (no registers to hold it beside the fragments): the DMA writes lane i's 16 bytes to position i, which in the
-        // swizzled row is logical segment s ^ key(pp), so that is the segment the lane fetches.  Rounds 1-3 are fetched into the
-        // (then dead) fragment registers when the epilogue starts, by inline asm: hipcc would sink plain loads to their uses
-        // (one exposed HBM round trip per round) and answer the first use with vmcnt(0).
-        auto res_src = [&](int r, int k, bool swizzled) __attribute__((always_inline)) -> const unsigned char* {
-            const int gy = y0 + 2 * w + (r >> 1), gyc = gy < H ? gy : H - 1;
+        // the residual of round r (= pixel block r of the wave), piece j: lane (q, c15) fetches its own share of pixel 4q + j, i.e. of
+        // z = cat(view i, partner) (64 channels = 128 bytes each) the 16 bytes that hold channels 8 c15 .. 8 c15 + 7
+        auto res_src = [&](int r, int j) __attribute__((always_inline)) -> const unsigned char* {
             int lq = lane;
             asm volatile("" : "+v"(lq));
-            const int pp = PPP * k + lq / SEGS;
-            const int kk = SEGS == 16 ? pp : ((pp & 7) ^ (pp >> 3));
-            const int s = swizzled ? (lq % SEGS) ^ kk : lq % SEGS;
-            const int gx = x0 + 16 * (r & 1) + pp, gxc = gx < W ? gx : W - 1;
-            const unsigned char* view = (RESM == 2 && s >= 8) ? resB : resA;
-            return view + (unsigned)((gyc * W + gxc) * 128 + (s & 7) * 16);
+            const int c15r = lq & 15, qr = lq >> 4;
+            const int gy = y0 + 2 * w + (r >> 1), gyc = gy < H ? gy : H - 1;
+            const int gx = x0 + 16 * (r & 1) + 4 * qr + j, gxc = gx < W ? gx : W - 1;
+            const unsigned char* view = (RESM == 2 && c15r >= 8) ? resB : resA;
+            if (V6_ABL & 64) return resA + ((unsigned)(((gyc * W + gxc) & 511) * 128) + (RESM == 2 ? (unsigned)((c15r & 7) * 16) : (unsigned)(c15r * LB)));
+            return view + ((unsigned)((gyc * W + gxc) * 128) + (RESM == 2 ? (unsigned)((c15r & 7) * 16) : (unsigned)(c15r * LB)));
         };
+        constexpr bool FIFO = RES && LB == 16;       // (there is no 8-byte LDS-DMA: the 64-cout layer fetches round 0 like the others)
+        // round 0 goes into the wave's 4 KB of LDS by DMA while the tile's last stage computes (no registers to hold it beside the
+        // fragments): lane i's 16 bytes land at piece j, position i, and that is where the lane reads them back
         auto res_dma0 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < NPC; ++k)
+            for (int j = 0; j < 4; ++j)
                 if (!(V6_ABL & 16))
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)res_src(0, k, true),
-                                                     (lds_ptr6)(smem + GEO::OFF_STG + w * GEO::STG_WAVE + k * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)res_src(0, j),
+                                                     (lds_ptr6)(smem + GEO::OFF_FIFO + w * GEO::FIFO_WAVE + j * 1024), 16, 0, 0);
         };
 
         for (int c = 0; c < 4; ++c) {
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                 static_assert(N_ITEMS <= NSTEP, "one DMA item per step");
                 int halo_out = 0;                                                      // halo pieces this wave leaves in flight
                 if (next_chunk) halo_out = tg == 0 ? 3 : tg == 1 ? n_in - 3 : 0;
-                if (RES && tg == 2 && c == 3 && !(V6_ABL & (2 | 128))) res_dma0();
+                if (FIFO && tg == 2 && c == 3 && !(V6_ABL & 2)) res_dma0();
                 // ---- NSTEP steps = 3 taps x NQ cout pairs, 8 MFMAs each ((k, pxb): cout block 2qt+k x pixel block pxb).
                 // Hand-issued fragment reads with counted waits: with an LDS-DMA anywhere in a kernel hipcc stops counting LDS waits
                 // and answers every fragment use with lgkmcnt(0), i.e. with the whole LDS latency.  Program order of the reads:
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                             else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[i & 1][1]));
                         } else if (k == 0) asm volatile("" : "+v"(fb[bs][pxb]));
                         if (V6_ABL & 1) asm volatile("" : "+v"(acc[qt * 2 + k][pxb]) : "v"(fa[i & 1][k]), "v"(fb[bs][pxb]));
-                        else acc[qt * 2 + k][pxb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][k], fb[bs][pxb], acc[qt * 2 + k][pxb], 0, 0, 0);
+                        else acc[qt * 2 + k][pxb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bs][pxb], fa[i & 1][k], acc[qt * 2 + k][pxb], 0, 0, 0);
                         if (g < 2 && a_next) load_a1(i + 1, g);
                         if (g >= 2 && g < 6 && b_cur) load_b1(tap + 1, g - 2);
                         if (g == 7 && i < N_ITEMS) issue_item(i);
@@ -423,96 +422,75 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                         for (int pxb = 0; pxb < 4; ++pxb) asm volatile("" :: "v"(acc[cb][pxb]));
                 }
                 if (tg == 2 && c == 3 && !(V6_ABL & 2)) {
-                    // ---- epilogue of this tile: registers, global memory and this wave's staging rows only
-                    unsigned char* stg = smem + GEO::OFF_STG + w * GEO::STG_WAVE;
-                    // round 1 now, round r + 2 when round r has retired its accumulators: more at once do not fit beside the 128
-                    // accumulators (hipcc then spills freshly loaded pieces, i.e. waits for them on the spot)
-                    u32x4 rq[4][NPC];
-                    auto res_load = [&](int r) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int k = 0; k < NPC; ++k) {
-                            const unsigned char* src = res_src(r, k, false);
-                            if (V6_ABL & 16) rq[r][k] = u32x4{(unsigned)lane, 1u, 2u, 3u};
-                            else rq[r][k] = *(const u32x4*)src;
-                        }
-                    };
-                    if (RES) {
-                        if (V6_ABL & 128) res_load(0);
-                        res_load(1);
-                    }
+                    // ---- epilogue of this tile: registers and global memory only.  The MFMAs ran with the PIXELS as the A operand, so
+                    // acc[cb][r][j] of lane (q, c15) is pixel 4q + j of pixel block r, channel NCB * c15 + cb: a lane's NCB values of one
+                    // pixel are LB contiguous bytes of that pixel's row, the 16 lanes of a q together one whole row, and one store (or
+                    // residual load) instruction covers four whole pixel rows - no LDS staging, no lane exchanges.
+                    // Nothing is in flight here (the counted wait above, halo_out == 0), but hipcc cannot see inline-asm waits: as long as it
+                    // believes an LDS-DMA pending it answers the first use of a plain load with vmcnt(0), i.e. with a wait for the rounds
+                    // issued behind it as well.  A wait it can see (free at this point) lets it count from here on.
+                    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
                     int le = lane;
                     asm volatile("" : "+v"(le));                    // every lane-derived address below is formed here, per tile
                     const int c15e = le & 15, qe = le >> 4;
-                    // a pixel's staging row holds its ROW bytes with the 16-byte segments XOR-ed by a per-pixel key
-                    const int key = SEGS == 16 ? c15e : ((c15e & 7) ^ (c15e >> 3));
+                    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)(hw * ROW), 0x00020000);
+                    lane_row_t rq[4][4];                                                      // [round][j]
+                    auto res_load = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (V6_ABL & 16) { rq[r][j] = lane_row_t{}; rq[r][j][0] = (unsigned)le; }
+                            else rq[r][j] = *(const lane_row_t*)res_src(r, j);
+                        }
+                    };
+                    // rounds 1 and 2 go into the (now dead) fragment registers, round 3 follows when round 0 is done
+                    if (RES) {
+                        if (FIFO) {
+                            res_load(1); res_load(2);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) rq[0][j] = *(const lane_row_t*)(smem + GEO::OFF_FIFO + w * GEO::FIFO_WAVE + j * 1024 + le * 16);
+                        } else { res_load(0); res_load(1); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);               // (hipcc would otherwise start all four rounds' loads here and spill them)
                     auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
                         constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int gy = y0 + 2 * w + (r >> 1);
-                            if (RES && (r > 0 || (V6_ABL & 128))) {
-                                // plain loads, waited for by hipcc (inline-asm loads were tried: hipcc copies their destination registers
-                                // in front of the hand-placed wait, i.e. before the data has landed)
 #pragma unroll
-                                for (int k = 0; k < NPC; ++k) {
-                                    const int pp = PPP * k + le / SEGS, s = le % SEGS;
-                                    const int kk = SEGS == 16 ? pp : ((pp & 7) ^ (pp >> 3));
-                                    *(u32x4*)(stg + pp * ROW + ((s ^ kk) << 4)) = rq[r][k];
+                            for (int j = 0; j < 4; ++j) {
+                                lane_row_t o, rv = rq[r][j];
+                                // (hipcc hoists whatever the two activation forms have in common above the branch between them - the
+                                // unpacked residual of every round in flight, i.e. a wait for all of them up front: keep the rare form apart)
+                                if (RES && ACT == 2) asm volatile("" : "+v"(rv));
+#pragma unroll
+                                for (int i = 0; i < NCB / 2; ++i) {
+                                    float xa = acc[2 * i][r][j], xb = acc[2 * i + 1][r][j];
+                                    // (the general form shares no subexpression with the fast one: hipcc hoists a common `slope * x` of all 128 values
+                                    // above the branch between the two and spills them)
+                                    if (ACT == 1) { xa = raw_max6(xa, act_slope * xa); xb = raw_max6(xb, act_slope * xb); }
+                                    else {
+                                        xa = __builtin_fmaf(act_slope, __builtin_fminf(xa, 0.f), __builtin_fmaxf(xa, 0.f));
+                                        xb = __builtin_fmaf(act_slope, __builtin_fminf(xb, 0.f), __builtin_fmaxf(xb, 0.f));
+                                    }
+                                    if (RES) {
+                                        const float ra = __uint_as_float(rv[i] << 16), rb = __uint_as_float(rv[i] & 0xffff0000u);
+                                        if (RESM == 3) { xa = ra + res_alpha * xa; xb = rb + res_alpha * xb; }
+                                        else { xa += ra; xb += rb; }
+                                    }
+                                    o[i] = pack2_bf16(xa, xb);
                                 }
+                                const int gx = x0 + 16 * (r & 1) + 4 * qe + j;
+                                // a pixel outside the image gets an offset the descriptor's range check drops: no branch around the store
+                                const unsigned voff = (unsigned)((gy * W + gx) * ROW + c15e * LB) | ((unsigned)(W - 1 - gx) & OOB6) | (gy < H ? 0u : OOB6);
+                                if (V6_ABL & 8) asm volatile("" :: "v"(o), "v"(voff));
+                                else if constexpr (LB == 16) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, 0, 0);
+                                else __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, 0, 0);
                             }
-                            // batched: all residual cells first, then the arithmetic, then all result cells, then the row pieces (with an
-                            // LDS-DMA in the kernel hipcc answers every LDS read's first use with lgkmcnt(0): one round trip per batch)
-                            unsigned cell[NCB];
-#pragma unroll
-                            for (int cb = 0; cb < NCB; ++cb) cell[cb] = (unsigned)(c15e * ROW + (((2 * cb + (qe >> 1)) ^ key) << 4) + (qe & 1) * 8);
-                            u32x2 rr[NCB];
-                            if (RES) {
-#pragma unroll
-                                for (int cb = 0; cb < NCB; ++cb) rr[cb] = *(const u32x2*)(stg + cell[cb]);
-                            }
-                            u32x2 o[NCB];
-#pragma unroll
-                            for (int cb = 0; cb < NCB; ++cb) {
-                                float x[4];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) x[e] = acc[cb][r][e];
-                                if (ACT == 1) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) x[e] = raw_max6(x[e], slope * x[e]);
-                                } else if (ACT == 2) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) x[e] = x[e] >= 0.f ? x[e] : slope * x[e];
-                                }
-                                if (RES) {
-                                    const float r0 = __uint_as_float(rr[cb][0] << 16), r1 = __uint_as_float(rr[cb][0] & 0xffff0000u);
-                                    const float r2 = __uint_as_float(rr[cb][1] << 16), r3 = __uint_as_float(rr[cb][1] & 0xffff0000u);
-                                    if (RESM == 3) { x[0] = r0 + res_alpha * x[0]; x[1] = r1 + res_alpha * x[1]; x[2] = r2 + res_alpha * x[2]; x[3] = r3 + res_alpha * x[3]; }
-                                    else { x[0] += r0; x[1] += r1; x[2] += r2; x[3] += r3; }
-                                }
-                                o[cb][0] = pack2_bf16(x[0], x[1]);
-                                o[cb][1] = pack2_bf16(x[2], x[3]);
-                            }
-#pragma unroll
-                            for (int cb = 0; cb < NCB; ++cb) *(u32x2*)(stg + cell[cb]) = o[cb];
-                            u32x4 vv[NPC];
-#pragma unroll
-                            for (int k = 0; k < NPC; ++k) {
-                                const int pp = PPP * k + le / SEGS, s = le % SEGS;
-                                const int kk = SEGS == 16 ? pp : ((pp & 7) ^ (pp >> 3));
-                                vv[k] = *(const u32x4*)(stg + pp * ROW + ((s ^ kk) << 4));
-                            }
-#pragma unroll
-                            for (int k = 0; k < NPC; ++k) {
-                                const int pp = PPP * k + le / SEGS, s = le % SEGS;
-                                const int gx = x0 + 16 * (r & 1) + pp;
-                                if (V6_ABL & 8) asm volatile("" :: "v"(vv[k]));
-                                else if (gy < H && gx < W) *(u32x4*)(outp + (unsigned)((gy * W + gx) * ROW + s * 16)) = vv[k];
-                            }
-                            if (RES && r < 2) res_load(r + 2);           // one round of work between a fetch and its use
+                            if (RES && (FIFO ? r == 0 : r < 2)) res_load(FIFO ? 3 : r + 2);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     };
-                    if (!has_slope) epilogue(std::integral_constant<int, 0>{});
-                    else if (slope01) epilogue(std::integral_constant<int, 1>{});
+                    if (slope01) epilogue(std::integral_constant<int, 1>{});          // max(x, slope * x): PReLU for 0 <= slope <= 1, identity at 1
                     else epilogue(std::integral_constant<int, 2>{});
                 }
 #ifdef V6_STAMP
