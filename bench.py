@@ -44,7 +44,7 @@ NETWORK = {   # reference config/config.json:8-34
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 FUSION_FAMILIES = ("conv3x3_bf16_128x128", "conv3x3_bf16_128x128+res", "conv3x3_bf16_128x64+res", "conv3x3_bf16_128x64")
-KERNEL_SOURCES = ("conv3x3_v6.hip", "conv3x3_v7.hip", "conv3x3_r64.hip", "stem.hip", "decoder.hip")
+KERNEL_SOURCES = ("conv3x3_v6.hip", "conv3x3_r64.hip", "stem.hip", "decoder.hip")
 
 
 def synth_inputs(batch, views, size, device, seed):

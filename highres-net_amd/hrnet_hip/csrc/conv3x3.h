@@ -35,12 +35,9 @@ int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream
 // bf16 64 -> 64 with LDS-resident weights (conv3x3_r64.hip); -100 = not applicable, caller picks another kernel.
 int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream);
 
-// bf16 128 -> {128, 64}, round 2: descriptor-based halo DMA issued from the MFMA gaps, LDS-staged epilogue (conv3x3_v6.hip);
-// -100 = not applicable.
+// bf16 128 -> {128, 64}: the three layers of a fusion level; descriptor-based halo DMA issued from the MFMA gaps, epilogue straight
+// from the accumulators in whole pixel rows (conv3x3_v6.hip); -100 = not applicable.
 int hrn_launch_conv3x3_v6(int cout, const ConvParams& p, hipStream_t stream);
-
-// bf16 128 -> {128, 64}: the conv3x3_v6 skeleton on v_mfma_f32_32x32x16_bf16 (conv3x3_v7.hip); -100 = not applicable.
-int hrn_launch_conv3x3_v7(int cout, const ConvParams& p, hipStream_t stream);
 
 // Pack OIHW f32 weights [cout][cin][3][3] into the kernel's step-major layout (device to device).
 int hrn_launch_conv_pack(int dt, int cin, int cout, const float* w_oihw, void* packed, hipStream_t stream);

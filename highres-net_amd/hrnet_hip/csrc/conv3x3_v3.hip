@@ -508,20 +508,12 @@ int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t st
         return offload ? launch_v3<64, 64, true>(p, stream) : launch_v3<64, 64, false>(p, stream);
     }
     if (cin == 128) {
-        // round 2: the same skeleton on two MFMA shapes, A/B-timed on one box (profiles/r02_v6_v7_ab.txt): conv3x3_v7.hip
-        // (32x32x16) wins the 128 -> 64 layer (0.481 vs 0.494 ms), conv3x3_v6.hip (16x16x32: higher clock) the 128 -> 128 layers
-        // (0.813 / 0.774 vs 0.848 / 0.802 ms).  HRN_CONV_V7 = 0: v6 everywhere, 1 (default): v7 for cout 64, 2: v7 everywhere
-        static int v7 = -1;
-        if (v7 < 0) { const char* e = getenv("HRN_CONV_V7"); v7 = e ? atoi(e) : 1; }
-        if (v7 >= (cout == 64 ? 1 : 2)) { const int rc = hrn_launch_conv3x3_v7(cout, p, stream); if (rc != -100) return rc; }
-    }
-    if (cin == 128) {
-        // round 2: conv3x3_v6.hip for the three layers of a fusion level; HRN_CONV_V6=0 falls back to v5 / v4 (A/B timing)
+        // conv3x3_v6.hip for the three layers of a fusion level; HRN_CONV_V6=0 runs this file's kernel instead (A/B timing)
         static int v6 = -1;
         if (v6 < 0) { const char* e = getenv("HRN_CONV_V6"); v6 = e ? atoi(e) : 1; }
         if (v6) { const int rc = hrn_launch_conv3x3_v6(cout, p, stream); if (rc != -100) return rc; }
     }
-    // what conv3x3_r64 / v6 / v7 decline (images beyond their 32-bit in-image offsets, > 8.3 Mpixel) runs on this file's kernel
+    // what conv3x3_r64 / v6 decline (images beyond their 32-bit in-image offsets, > 8.3 Mpixel) runs on this file's kernel
     if (cin == 128 && cout == 64) return offload ? launch_v3<128, 64, true>(p, stream) : launch_v3<128, 64, false>(p, stream);
     if (cin == 128 && cout == 128)
         return (offload && p.res_mode == 0) ? launch_v3<128, 128, true>(p, stream) : launch_v3<128, 128, false>(p, stream);

@@ -290,7 +290,7 @@ def test_errors_are_loud():
 
 @pytest.mark.parametrize("S,V", [(8, 2), (18, 2), (20, 3), (27, 3), (40, 5), (50, 2), (72, 4), (100, 2)])
 def test_bf16_kernels_on_awkward_sizes_vs_fp32_path(S, V):
-    """Image sides that are no multiple of any tile (conv3x3_v6 / v7: 16 x 32, conv3x3_r64 / v3: 8 x 32; LDS-DMA halo pieces that end
+    """Image sides that are no multiple of any tile (conv3x3_v6: 16 x 32, conv3x3_r64 / v3: 8 x 32; LDS-DMA halo pieces that end
     mid-row, EXEC-masked last pieces, partial store rows; widths that split a lane pair (27) or a lane quad (18, 50) of the
     coalescing lane exchanges in the epilogues): the bf16 kernels against the exact-fp32 path on the same inputs."""
     lrs, alphas = synth.fast_batch(40 + S, 2, V, S)
@@ -351,7 +351,7 @@ def test_forward_is_graph_capturable():
 
 @pytest.mark.parametrize("S,V", [(18, 2), (27, 3), (50, 4), (100, 2)])
 def test_bf16_stages_on_ragged_widths_vs_fp32_path(S, V):
-    """Stage by stage (encoder = conv3x3_r64, fusion = conv3x3_v6 / v7) at widths that cut lane pairs / quads of the epilogues'
+    """Stage by stage (encoder = conv3x3_r64, fusion = conv3x3_v6) at widths that cut lane pairs / quads of the epilogues'
     coalescing exchanges and leave partial tiles: every pixel of the bf16 stage outputs against the exact-fp32 path's, so that a
     mis-addressed piece at an image edge cannot hide in a whole-image PSNR."""
     lrs, alphas = synth.fast_batch(900 + S, 2, V, S)
