@@ -45,7 +45,8 @@
 #define V6_ABL 0
 #endif
 #ifndef V6_BAL
-#define V6_BAL 4          // eighths of a stage's steps during which waves 4-7 run at raised priority (0 = off)
+#define V6_BAL 4          // COUT = 128: eighths of a stage's steps during which waves 4-7 run at raised priority (0 = off; COUT = 64
+                          // runs without: A/B on one box, 0.454 vs 0.463 ms)
 #endif
 
 #ifdef V6_STAMP      // diagnostic build only (tools/stamps/read_v6.py): s_memtime stamps of tile 1 of the largest launch
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
     constexpr int OFF_IN = GEO::OFF_IN, ROW = GEO::ROW, LB = GEO::LB;
     typedef typename std::conditional<LB == 16, u32x4, u32x2>::type lane_row_t;       // a lane's share of one pixel's row
     constexpr bool RES = RESM != 0;
+    constexpr int BAL = COUT == 128 ? V6_BAL : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_lds = (float*)(smem + GEO::OFF_BIAS);
 
@@ -366,12 +368,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                 auto load_a1 = [&](int i, int k) __attribute__((always_inline)) {       // step i = (tap i / NQ, cout pair i % NQ)
                     rd(fa[i & 1][k], abase, (i / NQ) * TAP_BYTES + (i % NQ) * 2048 + k * 1024);
                 };
-#if V6_BAL
                 // the SIMD's arbiter prefers the older wave (w) to its partner (w + 4) all stage long: w finishes its 96 MFMAs in ~2.7 k
                 // cycles and then idles at the barrier while w + 4 runs alone at ~60 % of the pipe.  Priority for w + 4 during the first
                 // steps of the stage evens them out (stamps: profiles/r02_final_v6_stamps.txt)
-                if (w >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
+                if (BAL && w >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int pxb = 0; pxb < 4; ++pxb) load_b1(0, pxb);
                 load_a1(0, 0);
@@ -407,9 +407,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                         if (g < 2 && a_next) load_a1(i + 1, g);
                         if (g >= 2 && g < 6 && b_cur) load_b1(tap + 1, g - 2);
                         if (g == 7 && i < N_ITEMS) issue_item(i);
-#if V6_BAL
-                        if (g == 7 && i == (NSTEP * V6_BAL) / 8 - 1 && w >= 4) __builtin_amdgcn_s_setprio(0);
-#endif
+                        if (BAL && g == 7 && i == (NSTEP * BAL) / 8 - 1 && w >= 4) __builtin_amdgcn_s_setprio(0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
