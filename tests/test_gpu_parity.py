@@ -6,9 +6,12 @@
 Tolerances (BASELINE.json north_star: "within 1e-3 rel fp32"):
   fp32 path : max|hip - ref| / max|ref| <= 1e-3 is the contract; the exact-fp32 MFMA path is additionally held to
               2e-5 as a regression guard (measured ~2e-6).
-  bf16 path : bf16 storage cannot meet 1e-3; it is held to max-rel <= 4e-2 and PSNR(hip, ref) >= 42 dB
-              (measured ~1e-2 / 50-56 dB) and documented as such in DESIGN.md.
+  bf16 path : bf16 storage cannot meet 1e-3; it is held to max-rel <= 2.5e-2 and PSNR(hip, ref) >= 45 dB (measured over
+              the checks of this file: worst 1.35e-2 / 49.5 dB, typically 1e-2 / 52-56 dB; HRN_TEST_RECORD=file lists them)
+              and documented as such in DESIGN.md.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,7 +23,7 @@ import util
 pytestmark = pytest.mark.gpu
 
 FP32_CONTRACT, FP32_GUARD = 1e-3, 2e-5
-BF16_REL, BF16_PSNR = 4e-2, 42.0
+BF16_REL, BF16_PSNR = 2.5e-2, 45.0
 
 HR_CASES = ["hrnet_b1_v1_s16", "hrnet_b2_v5_s16", "hrnet_b2_v6_s16_pad", "hrnet_b1_v12_s24", "hrnet_b2_v4_s16_noalpha",
             "hrnet_b1_v32_s32"]
@@ -31,6 +34,9 @@ def _check(prec, got, want):
         e = util.rel_err(got, want)
         assert e <= FP32_CONTRACT and e <= FP32_GUARD, e
     else:
+        if os.environ.get("HRN_TEST_RECORD"):      # measured margins of the bf16 bounds: one line per check
+            with open(os.environ["HRN_TEST_RECORD"], "a") as f:
+                f.write(f"{util.rel_err(got, want):.4e} {util.psnr_db(got, want):.2f}\n")
         assert util.rel_err(got, want) <= BF16_REL and util.psnr_db(got, want) >= BF16_PSNR, (util.rel_err(got, want), util.psnr_db(got, want))
 
 
