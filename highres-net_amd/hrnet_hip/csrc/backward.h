@@ -6,9 +6,10 @@
 // bytes of the `scratch` buffer the launchers below share (wgrad partial slabs, reduction partials)
 size_t hrn_bwd_scratch_bytes(int num_cus);
 
-// g = dy * PReLU'(x) from the post-activation y; dslope[0] += sum dy * min(x, 0).  g may alias dy.  n elements, n % 4 == 0.
-int hrn_launch_prelu_bwd(const float* dy, const float* y, const float* slope, float* g, size_t n, float* dslope, void* scratch,
-                         hipStream_t s);
+// PReLU backward from the post-activation y (needs slope > 0) and the bias gradient of the convolution in front of it, in one pass:
+// g = dy * PReLU'(x) ([rows][C], C in {64, 128}; may alias dy), dslope[0] += sum dy * min(x, 0), db[c] += sum_rows g[row][c]
+int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* slope, float* g, size_t rows, int C, float* dslope,
+                              float* db, void* scratch, hipStream_t s);
 // db[c] += sum_rows g[row][c], C in {64, 128}
 int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scratch, hipStream_t s);
 // wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]: the OIHW tensor whose forward convolution is the data gradient

@@ -16,39 +16,15 @@
 #include "kernels.h"
 #include "backward.h"
 
+#ifndef WG_ABL
+#define WG_ABL 0        // timing-only ablations of conv_wgrad_kernel (results WRONG): 1 no prefetch of the next tile | 2 no LDS staging | 4 no operand reads
+#endif
+
 namespace {
 
 constexpr int RED_BLOCKS = 512;         // partial sums per reduction
 
-// ------------------------------------------------------------------------------------------------ PReLU backward
-__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                        const float* __restrict__ slope, float* __restrict__ g, size_t n4,
-                                                        double* __restrict__ partial) {
-    const float a = slope[0];
-    const float inv_a = a != 0.f ? 1.f / a : 0.f;
-    double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 d = ((const f32x4*)dy)[i], v = ((const f32x4*)y)[i];
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool pos = v[j] > 0.f;
-            o[j] = pos ? d[j] : a * d[j];
-            // the slope gradient is a sum of signed terms that largely cancel: accumulate it in fp64
-            if (!pos) acc += (double)d[j] * ((double)v[j] * (double)inv_a);
-        }
-        ((f32x4*)g)[i] = o;
-    }
-    __shared__ double red[256];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-
+// ------------------------------------------------------------------------------------------------ scalar reductions
 // out[0] += sum of partial[0..n): one 256-thread block, fixed summation tree (deterministic)
 __global__ __launch_bounds__(256) void scalar_finish_kernel(const double* __restrict__ partial, int n, float* __restrict__ out) {
     __shared__ double red[256];
@@ -96,6 +72,56 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
         }
     }
 }
+// PReLU backward and the bias gradient of the convolution in front of it in ONE pass over dy / y: g = dy * PReLU'(x),
+// colpart[blk][c] = this block's column sums of g, slopepart[blk] = its share of the slope gradient.  Thread mapping and summation
+// order of colsum_kernel (fixed: bit-reproducible); g may alias dy.
+template <int C>
+__global__ __launch_bounds__(256) void prelu_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ slope, float* __restrict__ g, size_t rows,
+                                                             double* __restrict__ colpart, double* __restrict__ slopepart) {
+    constexpr int C4 = C / 4, RP = 256 / C4;
+    const int c4 = threadIdx.x % C4, rp = threadIdx.x / C4;
+    const float a = slope[0];
+    const float inv_a = a != 0.f ? 1.f / a : 0.f;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, sacc = 0.0;
+    const size_t stride = (size_t)gridDim.x * RP;
+    auto one = [&](size_t r) __attribute__((always_inline)) {
+        const size_t o4 = r * C + c4 * 4;
+        const f32x4 d = *(const f32x4*)(dy + o4), v = *(const f32x4*)(y + o4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = v[j] > 0.f;
+            o[j] = pos ? d[j] : a * d[j];
+            acc[j] += (double)o[j];
+            if (!pos) sacc += (double)d[j] * ((double)v[j] * (double)inv_a);      // signed terms that largely cancel: fp64
+        }
+        *(f32x4*)(g + o4) = o;
+    };
+    size_t r = (size_t)blockIdx.x * RP + rp;
+    for (; r + stride < rows; r += 2 * stride) { one(r); one(r + stride); }
+    for (; r < rows; r += stride) one(r);
+    __shared__ double red[4][256];
+    __shared__ double sred[256];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[j][threadIdx.x] = acc[j];
+    sred[threadIdx.x] = sacc;
+    __syncthreads();
+    if (rp == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double t = 0.0;
+            for (int k = 0; k < RP; ++k) t += red[j][k * C4 + c4];
+            colpart[(size_t)blockIdx.x * C + c4 * 4 + j] = t;
+        }
+    }
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sred[threadIdx.x] += sred[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) slopepart[blockIdx.x] = sred[0];
+}
+
 // out[c] += sum over blocks of partial[b][c]: one block per 32 channels, 8 block-phases per channel, fixed order
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
     __shared__ double red[8][32];
@@ -160,8 +186,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
 
     // The next tile's x halo (340 px x 16 float4) and g tile (256 px x 16 float4) travel HBM -> registers while the current tile
     // is multiplied (one wave per SIMD: 512 registers, 144 of them accumulators), and registers -> LDS between two barriers.
-    constexpr int NXR = (WG_HH * WG_HW * 16 + 255) / 256, NGR = WG_TH * WG_TW * 16 / 256;      // 22, 16 float4 per thread
+    // Thread -> (pixel column tid / 16 of a 16-pixel segment, 16-byte part tid % 16); a load `it` is a (row, segment) pair that is the
+    // same for every thread, so its row test and row address are scalar and a load costs one add: x halo rows 0..9 x segments
+    // {0, 1} = halo columns 0..31 (20 loads), the two leftover columns 32, 33 of all ten rows in two more (thread -> its own row);
+    // g rows 0..7 x segments {0, 1} (16 loads).
+    constexpr int NXR = 2 * WG_HH + 2, NGR = 2 * WG_TH;        // 22, 16 float4 per thread
     f32x4 xreg[NXR], greg[NGR];
+    const int pcol = tid >> 4, part = tid & 15;
+    // leftover columns: element e = tid + 256 k (k = 0, 1) < 320 -> (row e / 32, column 32 + (e % 32) / 16, part e % 16)
+    const int lrow[2] = {tid >> 5, 8 + (tid >> 5)}, lcol = 32 + ((tid >> 4) & 1);
     auto issue = [&](long tl) __attribute__((always_inline)) {
         const int m = (int)(tl / tiles);
         const int t = (int)(tl - (long)m * tiles);
@@ -179,49 +212,66 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
             xpitch = p.cin;
         }
         const float* gb = p.g + (size_t)m * hw * p.cout + p.co_chunk * 64;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        // per-thread column tests and offsets of the two segments (and of the leftover column), once per tile
+        const int gx0 = x0 - 1 + pcol, gx1 = gx0 + 16, gxl = x0 - 1 + lcol;
+        const bool okx0 = (unsigned)gx0 < (unsigned)W, okx1 = (unsigned)gx1 < (unsigned)W, okxl = (unsigned)gxl < (unsigned)W;
+        const int xo0 = gx0 * xpitch + part * 4, xo1 = gx1 * xpitch + part * 4, xol = gxl * xpitch + part * 4;
 #pragma unroll
-        for (int it = 0; it < NXR; ++it) {
-            const int q = tid + it * 256;
-            const int pix = q >> 4, part = q & 15;
-            const int py = pix / WG_HW, px = pix - py * WG_HW;
-            const int gy = y0 + py - 1, gx = x0 + px - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < WG_HH * WG_HW * 16 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                v = *(const f32x4*)(xb + ((size_t)gy * W + gx) * xpitch + part * 4);
-            xreg[it] = v;
+        for (int row = 0; row < WG_HH; ++row) {
+            const int gy = y0 + row - 1;                        // uniform
+            const bool oky = (unsigned)gy < (unsigned)H;
+            const float* rb = xb + (size_t)(oky ? gy : 0) * W * xpitch;
+            xreg[2 * row] = (oky && okx0) ? *(const f32x4*)(rb + xo0) : zero;
+            xreg[2 * row + 1] = (oky && okx1) ? *(const f32x4*)(rb + xo1) : zero;
         }
 #pragma unroll
-        for (int it = 0; it < NGR; ++it) {                      // zero outside the image: those pixels contribute nothing
-            const int q = tid + it * 256;
-            const int pix = q >> 4, part = q & 15;
-            const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy < H && gx < W) v = *(const f32x4*)(gb + ((size_t)gy * W + gx) * p.cout + part * 4);
-            greg[it] = v;
+        for (int k = 0; k < 2; ++k) {
+            const int gy = y0 + lrow[k] - 1;
+            const bool ok = (k == 0 || tid < 64) && (unsigned)gy < (unsigned)H && okxl;
+            xreg[2 * WG_HH + k] = ok ? *(const f32x4*)(xb + (size_t)gy * W * xpitch + xol) : zero;
+        }
+        // g: zero outside the image (those pixels contribute nothing)
+        const int hx0 = x0 + pcol, hx1 = hx0 + 16;
+        const int go0 = hx0 * p.cout + part * 4, go1 = hx1 * p.cout + part * 4;
+#pragma unroll
+        for (int row = 0; row < WG_TH; ++row) {
+            const int gy = y0 + row;
+            const bool oky = gy < H;
+            const float* rb = gb + (size_t)(oky ? gy : 0) * W * p.cout;
+            greg[2 * row] = (oky && hx0 < W) ? *(const f32x4*)(rb + go0) : zero;
+            greg[2 * row + 1] = (oky && hx1 < W) ? *(const f32x4*)(rb + go1) : zero;
         }
     };
     if ((long)blockIdx.x < total) issue(blockIdx.x);
     for (long tl = blockIdx.x; tl < total; tl += gridDim.x) {
         __syncthreads();                                        // previous tile's MFMA reads are done
+        if (!(WG_ABL & 2) || tl == blockIdx.x) {
 #pragma unroll
-        for (int it = 0; it < NXR; ++it) {
-            const int q = tid + it * 256;
-            if (q < WG_HH * WG_HW * 16) *(f32x4*)(xs + (q >> 4) * WG_XP + (q & 15) * 4) = xreg[it];
-        }
+            for (int row = 0; row < WG_HH; ++row) {
+                *(f32x4*)(xs + (row * WG_HW + pcol) * WG_XP + part * 4) = xreg[2 * row];
+                *(f32x4*)(xs + (row * WG_HW + 16 + pcol) * WG_XP + part * 4) = xreg[2 * row + 1];
+            }
 #pragma unroll
-        for (int it = 0; it < NGR; ++it) {
-            const int q = tid + it * 256;
-            *(f32x4*)(gs + (q >> 4) * WG_GP + (q & 15) * 4) = greg[it];
+            for (int k = 0; k < 2; ++k)
+                if (k == 0 || tid < 64) *(f32x4*)(xs + (lrow[k] * WG_HW + lcol) * WG_XP + part * 4) = xreg[2 * WG_HH + k];
+#pragma unroll
+            for (int row = 0; row < WG_TH; ++row) {
+                *(f32x4*)(gs + (row * WG_TW + pcol) * WG_GP + part * 4) = greg[2 * row];
+                *(f32x4*)(gs + (row * WG_TW + 16 + pcol) * WG_GP + part * 4) = greg[2 * row + 1];
+            }
         }
         __syncthreads();
-        if (tl + gridDim.x < total) issue(tl + gridDim.x);      // in flight during this tile's MFMAs
+        if (!(WG_ABL & 1)) if (tl + gridDim.x < total) issue(tl + gridDim.x);      // in flight during this tile's MFMAs
         // 128 k-steps of two pixels: A[co = r][k = hh] = g[pixel 2s + hh][cb*32 + r], B[k = hh][ci = r] = x[pixel + tap][ib*32 + r]
         const float* ga = gs + hh * WG_GP + cb * 32 + r;
         const float* xa = xs + hh * WG_XP + ib * 32 + r;
         // operands of k-step s+1 are read while the nine MFMAs of k-step s run (the compiler otherwise waits for each
-        // k-step's ten ds_reads right in front of its MFMAs); sched_barrier pins the order
-        float a_cur, b_cur[9], a_nxt = 0.f, b_nxt[9];
+        // k-step's ten ds_reads right in front of its MFMAs; sched_barrier pins the order) and land in the OTHER of two operand
+        // sets: no register copies between k-steps
+        float a0, b0[9], a1 = 0.f, b1[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         auto fetch = [&](int s, float& a, float (&b)[9]) __attribute__((always_inline)) {
+            if (WG_ABL & 4) return;
             const int pp = 2 * s;                               // even pixel of the pair; both pixels share the tile row
             const int row = pp >> 5, col = pp & 31;
             a = ga[pp * WG_GP];
@@ -231,17 +281,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) b[ky * 3 + kx] = xr[(ky * WG_HW + kx) * WG_XP];
         };
-        fetch(0, a_cur, b_cur);
-#pragma unroll 2
-        for (int s = 0; s < 128; ++s) {
-            if (s + 1 < 128) fetch(s + 1, a_nxt, b_nxt);
-            __builtin_amdgcn_sched_barrier(0);
+        auto multiply = [&](float a, const float (&b)[9]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+        };
+        if (WG_ABL & 4) { a0 = a1 = ga[0]; for (int t = 0; t < 9; ++t) b0[t] = b1[t] = xa[t * WG_XP]; }
+        fetch(0, a0, b0);
+        for (int s = 0; s < 128; s += 2) {
+            fetch(s + 1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            a_cur = a_nxt;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
+            multiply(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < 128) fetch(s + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // partial[blk][tap][co 64][ci 64]; accumulator element (g4, j) of lane (r = ci column, hh) is row co = 8*g4 + 4*hh + j
@@ -306,17 +360,25 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         }
         __syncthreads();
         const float* gb = g + (size_t)m * hw * 64 + co;
-        for (int pix = q; pix < WG_TH * WG_TW; pix += 4) {
-            const int py = pix >> 5, px = pix & 31;
-            const int gy = y0 + py, gx = x0 + px;
-            if (gy >= H || gx >= W) continue;
-            const float gv = gb[((size_t)gy * W + gx) * 64];
+        // eight of the thread's 64 pixels at a time: their loads of g are in flight together (the loop is latency-bound otherwise);
+        // pixels outside the image contribute zero
+        for (int p8 = 0; p8 < WG_TH * WG_TW / 4; p8 += 8) {
+            float gv[8];
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int u = 0; u < 8; ++u) {
+                const int pix = q + 4 * (p8 + u), gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+                gv[u] = (gy < H && gx < W) ? gb[((size_t)gy * W + gx) * 64] : 0.f;
+            }
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+            for (int u = 0; u < 8; ++u) {
+                const int pix = q + 4 * (p8 + u), py = pix >> 5, px = pix & 31;
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) acc[c * 9 + ky * 3 + kx] += gv * tile[c][py + ky][px + kx];
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc[c * 9 + ky * 3 + kx] += gv[u] * tile[c][py + ky][px + kx];
+            }
         }
     }
     // partial[blk][q][co][18]
@@ -324,12 +386,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 18; ++k) out[k] = acc[k];
 }
-__global__ void stem_wgrad_finish_kernel(const float* __restrict__ partial, int nrows, float* __restrict__ dw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over 64 * 18, dw layout [co][c2][3][3] = co*18 + c*9 + tap
-    if (idx >= 64 * 18) return;
+// dw[idx] += sum over rows of partial[row][idx], idx over 64 * 18 (dw layout [co][c2][3][3] = co*18 + c*9 + tap): 16 outputs x 16 row
+// phases per workgroup, fixed order
+__global__ __launch_bounds__(256) void stem_wgrad_finish_kernel(const float* __restrict__ partial, int nrows, float* __restrict__ dw) {
+    __shared__ double red[16][16];
+    const int o = threadIdx.x & 15, ph = threadIdx.x >> 4, idx = blockIdx.x * 16 + o;
     double s = 0.0;
-    for (int b = 0; b < nrows; ++b) s += (double)partial[(size_t)b * 64 * 18 + idx];
-    dw[idx] += (float)s;
+    for (int b = ph; b < nrows; b += 16) s += (double)partial[(size_t)b * 64 * 18 + idx];
+    red[ph][o] = s;
+    __syncthreads();
+    if (ph == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][o];
+        dw[idx] += (float)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise helpers
@@ -397,16 +468,19 @@ int red_grid(size_t n4) {
 
 size_t hrn_bwd_scratch_bytes(int num_cus) {
     // wgrad partial slabs (one (cout chunk, cin chunk) pair at a time) + reduction partials
-    return (size_t)num_cus * 9 * 4096 * 4 + (size_t)RED_BLOCKS * 128 * 8 + 4096;
+    return (size_t)num_cus * 9 * 4096 * 4 + (size_t)RED_BLOCKS * (128 + 1) * 8 + 4096;
 }
 
-int hrn_launch_prelu_bwd(const float* dy, const float* y, const float* slope, float* g, size_t n, float* dslope, void* scratch,
-                         hipStream_t s) {
-    HRN_CHECK(n % 4 == 0, -2, "prelu_bwd: element count %zu not a multiple of 4", n);
-    double* partial = (double*)scratch;
+int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* slope, float* g, size_t rows, int C, float* dslope,
+                              float* db, void* scratch, hipStream_t s) {
+    HRN_CHECK(C == 64 || C == 128, -2, "prelu_bwd_bias: C must be 64 or 128 (got %d)", C);
+    double* colpart = (double*)scratch;
     const int blocks = RED_BLOCKS;
-    hipLaunchKernelGGL(prelu_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, y, slope, g, n / 4, partial);
-    hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, dslope);
+    double* slopepart = colpart + (size_t)blocks * 128;
+    if (C == 64) hipLaunchKernelGGL(prelu_bwd_bias_kernel<64>, dim3(blocks), dim3(256), 0, s, dy, y, slope, g, rows, colpart, slopepart);
+    else hipLaunchKernelGGL(prelu_bwd_bias_kernel<128>, dim3(blocks), dim3(256), 0, s, dy, y, slope, g, rows, colpart, slopepart);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(256), 0, s, colpart, blocks, C, db);
+    hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, slopepart, blocks, dslope);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -459,10 +533,10 @@ int hrn_launch_stem_wgrad(const float* in0, size_t stride0, const float* in1, in
 int hrn_launch_stem_wgrad_sub(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* sub,
                               const float* g, int M, int H, int W, float* dw, void* scratch, int num_cus, hipStream_t s) {
     const long tiles = (long)((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * M;
-    int grid = num_cus;
+    int grid = 4 * num_cus;                 // four workgroups per CU: the kernel waits on memory, not on arithmetic
     if (tiles < grid) grid = (int)tiles;
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, sub, g, M, H, W, (float*)scratch);
-    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3((64 * 18 + 255) / 256), dim3(256), 0, s, (const float*)scratch, grid * 4, dw);
+    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3(64 * 18 / 16), dim3(256), 0, s, (const float*)scratch, grid * 4, dw);
     HRN_LAUNCH_CHECK();
     return 0;
 }

@@ -94,23 +94,28 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* __restric
 }
 
 // ---- fc1: y[b][j] = relu(bias[j] + sum_k x[b][k] * w[j][k]),  K = 32768 (NHWC flatten: k = hw*128 + c), J = 1024.
-// One workgroup per output neuron streams its 128 KB weight row once per batch tile of 8 samples (x stays L2 resident).
+// One workgroup per FC_NJ = 4 output neurons streams their four 128 KB weight rows once per batch tile of FC_NB = 16 samples; x
+// (4 MB at B = 32) stays L2 resident and is read 1024 / FC_NJ times (it was once per NEURON: 4 GB of L2 reads, 2.0 ms).
 // mask (optional, train-mode dropout p=0.5): uint8 [B][32768] in the REFERENCE's flatten order c*256 + hw; x is scaled by 2*mask.
-constexpr int FC_K = 32768;
+// Summation order: thread-strided partial dot products, a fixed shuffle tree, then the four waves in order (bit-reproducible).
+constexpr int FC_K = 32768, FC_NJ = 4, FC_NB = 16;
 __global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                   const unsigned char* __restrict__ mask, float* __restrict__ y, int B) {
-    __shared__ float red[8][4];
-    const int j = blockIdx.x;
-    const f32x4* wr = (const f32x4*)(w + (size_t)j * FC_K);
+    __shared__ float red[FC_NJ][FC_NB][4];
+    const int j0 = blockIdx.x * FC_NJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b0 = 0; b0 < B; b0 += 8) {
-        float acc[8];
+    for (int b0 = 0; b0 < B; b0 += FC_NB) {
+        float acc[FC_NJ][FC_NB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int n = 0; n < FC_NJ; ++n)
+#pragma unroll
+            for (int i = 0; i < FC_NB; ++i) acc[n][i] = 0.f;
         for (int k4 = threadIdx.x; k4 < FC_K / 4; k4 += 256) {
-            const f32x4 wv = wr[k4];
+            f32x4 wv[FC_NJ];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int n = 0; n < FC_NJ; ++n) wv[n] = *(const f32x4*)(w + (size_t)(j0 + n) * FC_K + (size_t)k4 * 4);
+#pragma unroll
+            for (int i = 0; i < FC_NB; ++i) {
                 const int b = b0 + i;
                 if (b < B) {
                     f32x4 xv = *(const f32x4*)(x + (size_t)b * FC_K + (size_t)k4 * 4);
@@ -120,21 +125,27 @@ __global__ __launch_bounds__(256) void fc1_kernel(const float* __restrict__ x, c
 #pragma unroll
                         for (int e = 0; e < 4; ++e) xv[e] = mk[e * 256] ? xv[e] * 2.f : 0.f;
                     }
-                    acc[i] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+#pragma unroll
+                    for (int n = 0; n < FC_NJ; ++n) acc[n][i] += xv[0] * wv[n][0] + xv[1] * wv[n][1] + xv[2] * wv[n][2] + xv[3] * wv[n][3];
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v = acc[i];
+        for (int n = 0; n < FC_NJ; ++n)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) red[i][wave] = v;
-        }
+            for (int i = 0; i < FC_NB; ++i) {
+                float v = acc[n][i];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) red[n][i][wave] = v;
+            }
         __syncthreads();
-        if (threadIdx.x < 8 && b0 + threadIdx.x < B) {
-            const float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3] + bias[j];
-            y[(size_t)(b0 + threadIdx.x) * 1024 + j] = fmaxf(v, 0.f);
+        if (threadIdx.x < FC_NJ * FC_NB) {
+            const int n = threadIdx.x / FC_NB, i = threadIdx.x % FC_NB;
+            if (b0 + i < B) {
+                const float v = red[n][i][0] + red[n][i][1] + red[n][i][2] + red[n][i][3] + bias[j0 + n];
+                y[(size_t)(b0 + i) * 1024 + j0 + n] = fmaxf(v, 0.f);
+            }
         }
         __syncthreads();
     }
@@ -206,7 +217,7 @@ int hrn_launch_bn_act_pool(const float* x, const float* scale, const float* shif
 
 int hrn_launch_fc1(const float* x, const float* w, const float* b, const unsigned char* mask, float* y, int B, hipStream_t stream) {
     HrnProfScope prof("fc1", 2.0 * B * 1024 * 32768, 1024.0 * 32768 * 4 + (double)B * 32768 * 4, stream);
-    hipLaunchKernelGGL(fc1_kernel, dim3(1024), dim3(256), 0, stream, x, w, b, mask, y, B);
+    hipLaunchKernelGGL(fc1_kernel, dim3(1024 / FC_NJ), dim3(256), 0, stream, x, w, b, mask, y, B);
     HRN_LAUNCH_CHECK();
     return 0;
 }

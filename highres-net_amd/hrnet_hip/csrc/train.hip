@@ -209,19 +209,16 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
         float* y2 = G[4];                   // gB, later dz       [Mh][hw][128]
         if ((rc = hrn_launch_fuse_df(dsn, alphas, V, pair_last, half, alpha_residual, x1, hw, B, s))) return rc;
         // f = PReLU(convC(t2))
-        if ((rc = hrn_launch_prelu_bwd(x1, (const float*)at(tws, L.f[t]), Pr->fuse_out_a, x1, (size_t)Mh * hw * 64, mut(Gr->fuse_out_a), sc, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(x1, (const float*)at(tws, L.f[t]), Pr->fuse_out_a, x1, (size_t)Mh * hw, 64, mut(Gr->fuse_out_a), mut(Gr->fuse_out_b), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t2[t]), nullptr, 0, 0, 0, 0, x1, Mh, H, W, 128, 64, mut(Gr->fuse_out_w), sc, cus, s))) return rc;
-        if ((rc = hrn_launch_colsum(x1, (size_t)Mh * hw, 64, mut(Gr->fuse_out_b), sc, s))) return rc;
         if ((rc = conv_dgrad(128, 64, Pr->fuse_out_w, x1, y1, nullptr, Mh, H, W, tws, L, s))) return rc;
         // t2 = z + u, u = PReLU(convB(t1))
-        if ((rc = hrn_launch_prelu_bwd(y1, (const float*)at(tws, L.u[t]), Pr->fuse_res_a[1], y2, (size_t)Mh * hw * 128, mut(Gr->fuse_res_a[1]), sc, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(y1, (const float*)at(tws, L.u[t]), Pr->fuse_res_a[1], y2, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[1]), mut(Gr->fuse_res_b[1]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t1[t]), nullptr, 0, 0, 0, 0, y2, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[1]), sc, cus, s))) return rc;
-        if ((rc = hrn_launch_colsum(y2, (size_t)Mh * hw, 128, mut(Gr->fuse_res_b[1]), sc, s))) return rc;
         if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[1], y2, y3, nullptr, Mh, H, W, tws, L, s))) return rc;
         // t1 = PReLU(convA(z))
-        if ((rc = hrn_launch_prelu_bwd(y3, (const float*)at(tws, L.t1[t]), Pr->fuse_res_a[0], y3, (size_t)Mh * hw * 128, mut(Gr->fuse_res_a[0]), sc, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(y3, (const float*)at(tws, L.t1[t]), Pr->fuse_res_a[0], y3, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[0]), mut(Gr->fuse_res_b[0]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad(nullptr, st, 1, half, pair_last, n, y3, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[0]), sc, cus, s))) return rc;
-        if ((rc = hrn_launch_colsum(y3, (size_t)Mh * hw, 128, mut(Gr->fuse_res_b[0]), sc, s))) return rc;
         if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[0], y3, y2, y1, Mh, H, W, tws, L, s))) return rc;     // dz = d t2 + dgradA(gA)
         // dz -> the two views of each pair (+ the alice pass-through)
         if ((rc = hrn_launch_fuse_scatter(dsn, y2, n, half, pair_last, alpha_residual, ds, hw, B, s))) return rc;
@@ -238,20 +235,17 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
     float* e3 = G[3];
     for (int l = nl - 1; l >= 0; --l) {
         // a_{l+1} = a_l + r_l,  r_l = PReLU(conv2(h_l)),  h_l = PReLU(conv1(a_l))
-        if ((rc = hrn_launch_prelu_bwd(dA, (const float*)at(tws, L.r[l]), Pr->enc_res_a[2 * l + 1], e2, (size_t)M * hw * 64, mut(Gr->enc_res_a[2 * l + 1]), sc, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.r[l]), Pr->enc_res_a[2 * l + 1], e2, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l + 1]), mut(Gr->enc_res_b[2 * l + 1]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.h[l]), nullptr, 0, 0, 0, 0, e2, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l + 1]), sc, cus, s))) return rc;
-        if ((rc = hrn_launch_colsum(e2, (size_t)M * hw, 64, mut(Gr->enc_res_b[2 * l + 1]), sc, s))) return rc;
         if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l + 1], e2, e3, nullptr, M, H, W, tws, L, s))) return rc;
-        if ((rc = hrn_launch_prelu_bwd(e3, (const float*)at(tws, L.h[l]), Pr->enc_res_a[2 * l], e3, (size_t)M * hw * 64, mut(Gr->enc_res_a[2 * l]), sc, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(e3, (const float*)at(tws, L.h[l]), Pr->enc_res_a[2 * l], e3, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l]), mut(Gr->enc_res_b[2 * l]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.a[l]), nullptr, 0, 0, 0, 0, e3, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l]), sc, cus, s))) return rc;
-        if ((rc = hrn_launch_colsum(e3, (size_t)M * hw, 64, mut(Gr->enc_res_b[2 * l]), sc, s))) return rc;
         if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l], e3, e2, dA, M, H, W, tws, L, s))) return rc;       // d a_l = d a_{l+1} + dgrad1(g1)
         float* tmp = dA; dA = e2; e2 = tmp;
     }
     // stem: a_0 = PReLU(conv(cat(view, reference frame)))                               HRNet.py:200-204, :51-53
-    if ((rc = hrn_launch_prelu_bwd(dA, (const float*)at(tws, L.a[0]), Pr->enc_init_a, dA, (size_t)M * hw * 64, mut(Gr->enc_init_a), sc, s))) return rc;
-    if ((rc = hrn_launch_stem_wgrad(lrs, hw, (const float*)at(tws, L.ref), V, hw, dA, M, H, W, mut(Gr->enc_init_w), sc, cus, s))) return rc;
-    return hrn_launch_colsum(dA, (size_t)M * hw, 64, mut(Gr->enc_init_b), sc, s);
+    if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.a[0]), Pr->enc_init_a, dA, (size_t)M * hw, 64, mut(Gr->enc_init_a), mut(Gr->enc_init_b), sc, s))) return rc;
+    return hrn_launch_stem_wgrad(lrs, hw, (const float*)at(tws, L.ref), V, hw, dA, M, H, W, mut(Gr->enc_init_w), sc, cus, s);
 }
 
 }  // extern "C"
