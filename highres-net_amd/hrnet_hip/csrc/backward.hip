@@ -74,20 +74,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 }
 // PReLU backward and the bias gradient of the convolution in front of it in ONE pass over dy / y: g = dy * PReLU'(x),
 // colpart[blk][c] = this block's column sums of g, slopepart[blk] = its share of the slope gradient.  Thread mapping and summation
-// order of colsum_kernel (fixed: bit-reproducible); g may alias dy.
+// order of colsum_kernel (fixed: bit-reproducible); g may alias dy.  With a positive slope the sign of x is the sign of the stored
+// post-activation y and x = y / slope where it is negative; otherwise (decided here, on the device: no host round trip) the
+// pre-activation itself is read from xpre, which the caller has recomputed under the same condition.
 template <int C>
 __global__ __launch_bounds__(256) void prelu_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             const float* __restrict__ slope, float* __restrict__ g, size_t rows,
-                                                             double* __restrict__ colpart, double* __restrict__ slopepart) {
+                                                             const float* __restrict__ xpre, const float* __restrict__ slope,
+                                                             float* __restrict__ g, size_t rows, double* __restrict__ colpart,
+                                                             double* __restrict__ slopepart) {
     constexpr int C4 = C / 4, RP = 256 / C4;
     const int c4 = threadIdx.x % C4, rp = threadIdx.x / C4;
     const float a = slope[0];
-    const float inv_a = a != 0.f ? 1.f / a : 0.f;
+    const bool from_y = a > 0.f;
+    const float* __restrict__ src = from_y ? y : xpre;
+    const float inv_a = from_y ? 1.f / a : 1.f;
     double acc[4] = {0.0, 0.0, 0.0, 0.0}, sacc = 0.0;
     const size_t stride = (size_t)gridDim.x * RP;
     auto one = [&](size_t r) __attribute__((always_inline)) {
         const size_t o4 = r * C + c4 * 4;
-        const f32x4 d = *(const f32x4*)(dy + o4), v = *(const f32x4*)(y + o4);
+        const f32x4 d = *(const f32x4*)(dy + o4), v = *(const f32x4*)(src + o4);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -471,14 +476,14 @@ size_t hrn_bwd_scratch_bytes(int num_cus) {
     return (size_t)num_cus * 9 * 4096 * 4 + (size_t)RED_BLOCKS * (128 + 1) * 8 + 4096;
 }
 
-int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* slope, float* g, size_t rows, int C, float* dslope,
-                              float* db, void* scratch, hipStream_t s) {
+int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* xpre, const float* slope, float* g, size_t rows, int C,
+                              float* dslope, float* db, void* scratch, hipStream_t s) {
     HRN_CHECK(C == 64 || C == 128, -2, "prelu_bwd_bias: C must be 64 or 128 (got %d)", C);
     double* colpart = (double*)scratch;
     const int blocks = RED_BLOCKS;
     double* slopepart = colpart + (size_t)blocks * 128;
-    if (C == 64) hipLaunchKernelGGL(prelu_bwd_bias_kernel<64>, dim3(blocks), dim3(256), 0, s, dy, y, slope, g, rows, colpart, slopepart);
-    else hipLaunchKernelGGL(prelu_bwd_bias_kernel<128>, dim3(blocks), dim3(256), 0, s, dy, y, slope, g, rows, colpart, slopepart);
+    if (C == 64) hipLaunchKernelGGL(prelu_bwd_bias_kernel<64>, dim3(blocks), dim3(256), 0, s, dy, y, xpre, slope, g, rows, colpart, slopepart);
+    else hipLaunchKernelGGL(prelu_bwd_bias_kernel<128>, dim3(blocks), dim3(256), 0, s, dy, y, xpre, slope, g, rows, colpart, slopepart);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(256), 0, s, colpart, blocks, C, db);
     hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, slopepart, blocks, dslope);
     HRN_LAUNCH_CHECK();

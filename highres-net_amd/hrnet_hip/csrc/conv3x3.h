@@ -24,6 +24,8 @@ struct ConvParams {
     int alpha_vs, res_vs;
     int relu;                         // 1: y = max(y, 0) after bias (ShiftNet eval with folded BN uses scale/shift below)
     const float* scale;               // optional per-channel scale applied before bias (folded BatchNorm), null = 1
+    const float* only_if_nonpos;      // f32 kernel only: when set, the launch does nothing unless only_if_nonpos[0] <= 0 (the backward's
+                                      // recomputation of a pre-activation, needed only behind a PReLU whose slope is not positive)
 };
 
 // Number of packed weight elements of one conv layer (== cin*cout*9).

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256 * (COUT / 64), 2) void conv3x3_kernel(const Con
     constexpr int W_BUF_BYTES = COUT * W_ROW_PITCH;         // one weight slice: [COUT][128 B of K], padded rows
     constexpr int N_IN_ITERS = (N_IN_CHUNKS16 + NT - 1) / NT;
 
+    if (p.only_if_nonpos && p.only_if_nonpos[0] > 0.f) return;          // uniform: before any barrier
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;    // half: which 64 output channels
     const int r = lane & 31, hh = lane >> 5;

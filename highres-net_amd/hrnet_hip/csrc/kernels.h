@@ -9,6 +9,8 @@ int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, 
 int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1,
                     const float* sub, const float* w, const float* bias, const float* slope, void* out,
                     int M, int H, int W, hipStream_t stream);
+int hrn_launch_stem_pre(const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1, const float* w,
+                        const float* bias, float* out, int M, int H, int W, const float* only_if_nonpos, hipStream_t stream);
 int hrn_launch_plane_mean(const float* x, float* mean, int planes, size_t hw, hipStream_t stream);
 
 // ---- decoder.hip

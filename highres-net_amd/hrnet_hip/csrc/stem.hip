@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0
                                                    const float* __restrict__ sub,   // [M][2] per-plane means or null
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ slope, void* __restrict__ out,
-                                                   int M, int H, int W) {
+                                                   int M, int H, int W, const float* __restrict__ only_if_nonpos) {
+    if (only_if_nonpos && only_if_nonpos[0] > 0.f) return;      // (ConvParams::only_if_nonpos)
     __shared__ __attribute__((aligned(16))) float wl[18 * 64];
     __shared__ __attribute__((aligned(16))) float bl[64];
     for (int i = threadIdx.x; i < 18 * 64; i += 256) {
@@ -281,9 +282,22 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(mblocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, w, bias, slope,
                            (unsigned short*)out, M, H, W);
     } else if (dt == HRN_BF16)
-        hipLaunchKernelGGL(stem_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W);
+        hipLaunchKernelGGL(stem_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W,
+                           (const float*)nullptr);
     else
-        hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W);
+        hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W,
+                           (const float*)nullptr);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+// f32, no activation, and only if only_if_nonpos[0] <= 0: the stem's pre-activation for the backward of a PReLU whose slope is not positive
+int hrn_launch_stem_pre(const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1, const float* w,
+                        const float* bias, float* out, int M, int H, int W, const float* only_if_nonpos, hipStream_t stream) {
+    const size_t patches = (size_t)M * ((H + 3) / 4) * ((W + 31) / 32);
+    const int blocks = (int)(patches < 16384 ? patches : 16384);
+    hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, (const float*)nullptr, w, bias,
+                       (const float*)nullptr, (void*)out, M, H, W, only_if_nonpos);
     HRN_LAUNCH_CHECK();
     return 0;
 }

@@ -26,19 +26,12 @@ struct TrainWs {
     size_t ref, a[HRN_MAX_RES_LAYERS + 1], h[HRN_MAX_RES_LAYERS], r[HRN_MAX_RES_LAYERS];
     size_t stack[TMAX + 1], t1[TMAX], u[TMAX], t2[TMAX], f[TMAX];
     size_t g[5];                            // backward: five gradient buffers of one full activation each
+    size_t xpre;                            // backward: a recomputed pre-activation (used only behind a PReLU whose slope is <= 0)
     size_t wt, wtp, zero_bias, scratch;
     size_t total;
 };
 
-int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, c = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) n = c;
-        else n = 256;
-    }
-    return n;
-}
+int num_cus() { return hrn_device_cus(); }
 
 TrainWs train_ws(int nl, int B, int V, int H, int W) {
     TrainWs w;
@@ -64,6 +57,7 @@ TrainWs train_ws(int nl, int B, int V, int H, int W) {
     }
     w.T = T;
     for (int i = 0; i < 5; ++i) w.g[i] = take(S);
+    w.xpre = take(S);
     w.wt = take((size_t)128 * 128 * 9 * 4);
     w.wtp = take((size_t)128 * 128 * 9 * 4);
     w.zero_bias = take(128 * 4);
@@ -190,6 +184,16 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
     HRN_HIP(hipMemsetAsync(at(tws, L.zero_bias), 0, 128 * 4, s));
     // gradients are handed over as mutable buffers in a params-shaped struct
     auto mut = [](const float* p) { return const_cast<float*>(p); };
+    // PReLU backward works from the stored post-activation while the slope is positive.  For a slope <= 0 (the reference allows any)
+    // the pre-activation is recomputed into `xpre` by the forward kernel without activation - a launch that does nothing unless the
+    // slope on the device says so (ConvParams::only_if_nonpos): no host round trip, ~3 us per PReLU in the usual case.
+    const HrnetLayout P = hrnet_layout(HRN_F32, nl);
+    float* xpre = (float*)at(tws, L.xpre);
+    auto pre = [&](int cin, int cout, const void* x, const void* wpk, const float* bias, const float* slope, int Mi) -> int {
+        ConvParams q = conv_base(Mi, H, W);
+        q.in = x; q.out = xpre; q.wpk = wpk; q.bias = bias; q.only_if_nonpos = slope;
+        return hrn_launch_conv3x3(HRN_F32, cin, cout, q, s);
+    };
 
     // ---- decoder: d_sr -> d stack_T (one view left)                                  HRNet.py:147-156,167-169
     float* dsn = G[0];                      // gradient of the views leaving the current level
@@ -209,15 +213,23 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
         float* y2 = G[4];                   // gB, later dz       [Mh][hw][128]
         if ((rc = hrn_launch_fuse_df(dsn, alphas, V, pair_last, half, alpha_residual, x1, hw, B, s))) return rc;
         // f = PReLU(convC(t2))
-        if ((rc = hrn_launch_prelu_bwd_bias(x1, (const float*)at(tws, L.f[t]), Pr->fuse_out_a, x1, (size_t)Mh * hw, 64, mut(Gr->fuse_out_a), mut(Gr->fuse_out_b), sc, s))) return rc;
+        if ((rc = pre(128, 64, at(tws, L.t2[t]), at(pk, P.fout_w), (const float*)at(pk, P.fout_b), Pr->fuse_out_a, Mh))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(x1, (const float*)at(tws, L.f[t]), xpre, Pr->fuse_out_a, x1, (size_t)Mh * hw, 64, mut(Gr->fuse_out_a), mut(Gr->fuse_out_b), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t2[t]), nullptr, 0, 0, 0, 0, x1, Mh, H, W, 128, 64, mut(Gr->fuse_out_w), sc, cus, s))) return rc;
         if ((rc = conv_dgrad(128, 64, Pr->fuse_out_w, x1, y1, nullptr, Mh, H, W, tws, L, s))) return rc;
         // t2 = z + u, u = PReLU(convB(t1))
-        if ((rc = hrn_launch_prelu_bwd_bias(y1, (const float*)at(tws, L.u[t]), Pr->fuse_res_a[1], y2, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[1]), mut(Gr->fuse_res_b[1]), sc, s))) return rc;
+        if ((rc = pre(128, 128, at(tws, L.t1[t]), at(pk, P.fres_w[1]), (const float*)at(pk, P.fres_b[1]), Pr->fuse_res_a[1], Mh))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(y1, (const float*)at(tws, L.u[t]), xpre, Pr->fuse_res_a[1], y2, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[1]), mut(Gr->fuse_res_b[1]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t1[t]), nullptr, 0, 0, 0, 0, y2, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[1]), sc, cus, s))) return rc;
         if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[1], y2, y3, nullptr, Mh, H, W, tws, L, s))) return rc;
         // t1 = PReLU(convA(z))
-        if ((rc = hrn_launch_prelu_bwd_bias(y3, (const float*)at(tws, L.t1[t]), Pr->fuse_res_a[0], y3, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[0]), mut(Gr->fuse_res_b[0]), sc, s))) return rc;
+        {
+            ConvParams q = conv_base(Mh, H, W);
+            q.in_pair = 1; q.stack = st; q.pair_h = half; q.pair_last = pair_last; q.pair_vs = n;
+            q.out = xpre; q.wpk = at(pk, P.fres_w[0]); q.bias = (const float*)at(pk, P.fres_b[0]); q.only_if_nonpos = Pr->fuse_res_a[0];
+            if ((rc = hrn_launch_conv3x3(HRN_F32, 128, 128, q, s))) return rc;
+        }
+        if ((rc = hrn_launch_prelu_bwd_bias(y3, (const float*)at(tws, L.t1[t]), xpre, Pr->fuse_res_a[0], y3, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[0]), mut(Gr->fuse_res_b[0]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad(nullptr, st, 1, half, pair_last, n, y3, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[0]), sc, cus, s))) return rc;
         if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[0], y3, y2, y1, Mh, H, W, tws, L, s))) return rc;     // dz = d t2 + dgradA(gA)
         // dz -> the two views of each pair (+ the alice pass-through)
@@ -235,16 +247,20 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
     float* e3 = G[3];
     for (int l = nl - 1; l >= 0; --l) {
         // a_{l+1} = a_l + r_l,  r_l = PReLU(conv2(h_l)),  h_l = PReLU(conv1(a_l))
-        if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.r[l]), Pr->enc_res_a[2 * l + 1], e2, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l + 1]), mut(Gr->enc_res_b[2 * l + 1]), sc, s))) return rc;
+        if ((rc = pre(64, 64, at(tws, L.h[l]), at(pk, P.enc_w[2 * l + 1]), (const float*)at(pk, P.enc_b[2 * l + 1]), Pr->enc_res_a[2 * l + 1], M))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.r[l]), xpre, Pr->enc_res_a[2 * l + 1], e2, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l + 1]), mut(Gr->enc_res_b[2 * l + 1]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.h[l]), nullptr, 0, 0, 0, 0, e2, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l + 1]), sc, cus, s))) return rc;
         if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l + 1], e2, e3, nullptr, M, H, W, tws, L, s))) return rc;
-        if ((rc = hrn_launch_prelu_bwd_bias(e3, (const float*)at(tws, L.h[l]), Pr->enc_res_a[2 * l], e3, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l]), mut(Gr->enc_res_b[2 * l]), sc, s))) return rc;
+        if ((rc = pre(64, 64, at(tws, L.a[l]), at(pk, P.enc_w[2 * l]), (const float*)at(pk, P.enc_b[2 * l]), Pr->enc_res_a[2 * l], M))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(e3, (const float*)at(tws, L.h[l]), xpre, Pr->enc_res_a[2 * l], e3, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l]), mut(Gr->enc_res_b[2 * l]), sc, s))) return rc;
         if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.a[l]), nullptr, 0, 0, 0, 0, e3, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l]), sc, cus, s))) return rc;
         if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l], e3, e2, dA, M, H, W, tws, L, s))) return rc;       // d a_l = d a_{l+1} + dgrad1(g1)
         float* tmp = dA; dA = e2; e2 = tmp;
     }
     // stem: a_0 = PReLU(conv(cat(view, reference frame)))                               HRNet.py:200-204, :51-53
-    if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.a[0]), Pr->enc_init_a, dA, (size_t)M * hw, 64, mut(Gr->enc_init_a), mut(Gr->enc_init_b), sc, s))) return rc;
+    if ((rc = hrn_launch_stem_pre(lrs, hw, (const float*)at(tws, L.ref), V, hw, (const float*)at(pk, P.stem_w), (const float*)at(pk, P.stem_b), xpre, M, H, W,
+                                  Pr->enc_init_a, s))) return rc;
+    if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.a[0]), xpre, Pr->enc_init_a, dA, (size_t)M * hw, 64, mut(Gr->enc_init_a), mut(Gr->enc_init_b), sc, s))) return rc;
     return hrn_launch_stem_wgrad(lrs, hw, (const float*)at(tws, L.ref), V, hw, dA, M, H, W, mut(Gr->enc_init_w), sc, cus, s);
 }
 

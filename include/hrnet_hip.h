@@ -100,7 +100,8 @@ int hrn_decoder_forward(const void* packed, int dtype, int num_layers, const voi
  * ACCUMULATES (+=, like autograd's .grad) the parameter gradients into the buffers `grads` points at - the same struct,
  * fields aliasing f32 gradient tensors of the parameters' shapes (the inputs lrs / alphas get no gradient, as in
  * train.py).  `packed` is the HRN_DTYPE_F32 blob of hrn_hrnet_pack, `params` the raw reference-layout tensors.
- * PReLU slopes must be > 0 (the backward works from stored post-activations). */
+ * Any PReLU slope is accepted, as in the reference: with a positive slope the backward works from the stored post-activations;
+ * behind a slope <= 0 it recomputes the pre-activation (decided on the device: the extra launches exit at once otherwise). */
 size_t hrn_hrnet_train_workspace_bytes(int num_layers, int B, int V, int H, int W);
 int hrn_hrnet_forward_train(const void* packed, int num_layers, int alpha_residual, const float* lrs, const float* alphas,
                             int B, int V, int H, int W, float* sr, void* train_ws, size_t train_ws_bytes, void* stream);

@@ -16,17 +16,21 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _fresh_model(alpha_residual=True, seed=1234):
+def _fresh_model(alpha_residual=True, seed=1234, slopes=None):
     from DeepNetworks.HRNet import HRNet
     cfg = {k: dict(v) for k, v in weights.HRNET_CONFIG.items()}
     cfg["recursive"]["alpha_residual"] = alpha_residual
     m = HRNet(cfg)
-    m.load_state_dict(weights.to_torch_state(weights.hrnet_state(seed)))
+    st = weights.to_torch_state(weights.hrnet_state(seed))
+    st.update({k: torch.full_like(st[k], v) for k, v in (slopes or {}).items()})
+    m.load_state_dict(st)
     return m.cuda().train()
 
 
-def _oracle_grads(lrs, alphas, cot, alpha_residual, seed=1234):
-    st = {k: v.double().requires_grad_(True) for k, v in weights.to_torch_state(weights.hrnet_state(seed)).items()}
+def _oracle_grads(lrs, alphas, cot, alpha_residual, seed=1234, slopes=None):
+    st = weights.to_torch_state(weights.hrnet_state(seed))
+    st.update({k: torch.full_like(st[k], v) for k, v in (slopes or {}).items()})
+    st = {k: v.double().requires_grad_(True) for k, v in st.items()}
     abs_terms = {}
     torch_port.ABS_TERMS = abs_terms             # sum |terms| of every single-slope / final-bias gradient (oracle/torch_port.py)
     try:
@@ -156,13 +160,45 @@ def test_hrnet_train_step_reduces_loss():
     assert float(after) < losses[0]
 
 
-def test_hrnet_backward_rejects_nonpositive_slope():
-    m = _fresh_model()
+NONPOS = {"encode.init_layer.1.weight": -0.2, "encode.res_layers.0.block.1.weight": 0.0, "encode.res_layers.0.block.3.weight": -0.05,
+          "encode.res_layers.1.block.3.weight": -0.3, "fuse.fuse.0.block.1.weight": -0.1, "fuse.fuse.0.block.3.weight": 0.0,
+          "fuse.fuse.2.weight": -0.25, "decode.deconv.1.weight": -0.1}
+
+
+@pytest.mark.parametrize("slopes", [NONPOS, {"fuse.fuse.2.weight": -0.25}, {"encode.res_layers.1.block.1.weight": 1.5}])
+def test_hrnet_backward_with_nonpositive_slopes(slopes):
+    """nn.PReLU puts no constraint on its slope and training can drive one through zero.  With a positive slope the HIP backward reads
+    the sign of the pre-activation off the stored post-activation; behind a slope <= 0 that is impossible (y >= 0 on both branches),
+    and the backward recomputes the pre-activation - decided per PReLU ON THE DEVICE.  Every PReLU of the model at a non-positive
+    slope (negative and exactly zero), one alone, and a slope above one (positive: the stored-activation path): forward and every
+    gradient against fp64 autograd on the port."""
+    B, V, S = 2, 5, 16
+    lrs, alphas, _ = synth.make_batch(5, B, V, S, 4)
+    rng = np.random.Generator(np.random.PCG64(78))
+    cot = rng.standard_normal((B, 1, 3 * S, 3 * S)).astype(np.float32)
+    want_sr, want = _oracle_grads(lrs, alphas, cot, True, slopes=slopes)
+    m = _fresh_model(True, slopes=slopes)
+    sr = m(util.dev(lrs), util.dev(alphas))
+    assert util.rel_err(sr.detach().cpu().numpy(), want_sr) <= 2e-5
+    (sr * util.dev(cot)).sum().backward()
+    abs_terms = want["__abs_terms__"]
+    for k, p in m.named_parameters():
+        got = p.grad.cpu().numpy()
+        if p.numel() == 1:
+            bound = 2e-5 * abs_terms.get(k, 0.0) + 1e-12
+            assert abs(float(got.ravel()[0]) - float(want[k].ravel()[0])) <= bound, (k, got, want[k], abs_terms.get(k))
+        else:
+            e = util.rel_err(got, want[k])
+            assert e <= 2e-4, (k, e)
+    # and the bf16 inference kernels take the same slopes (one activation path for every slope: conv3x3_v6 / conv3x3_r64)
     with torch.no_grad():
-        m.decode.deconv[1].weight.fill_(-0.1)
-    lrs, alphas, _ = synth.make_batch(5, 1, 2, 16, 2)
-    with pytest.raises(NotImplementedError):
-        m(util.dev(lrs), util.dev(alphas))
+        from DeepNetworks.HRNet import HRNet
+        cfg = {k: dict(v) for k, v in weights.HRNET_CONFIG.items()}
+        cfg["precision"] = "bf16"
+        mb = HRNet(cfg)
+        mb.load_state_dict(m.state_dict())
+        got = mb.cuda().eval()(util.dev(lrs), util.dev(alphas)).cpu().numpy()
+    assert util.rel_err(got, want_sr) <= 4e-2
 
 
 # ----------------------------------------------------------------------------- Lanczos shift backward
