@@ -44,6 +44,9 @@
 #ifndef V6_ABL
 #define V6_ABL 0
 #endif
+#ifndef V6_ST_AUX
+#define V6_ST_AUX 2        // cache policy of the output stores: 2 = nt (the next launch reads them from HBM anyway: A/B -0.5..-1 %)
+#endif
 #ifndef V6_BAL
 #define V6_BAL 4          // COUT = 128: eighths of a stage's steps during which waves 4-7 run at raised priority (0 = off; COUT = 64
                           // runs without: A/B on one box, 0.454 vs 0.463 ms)
@@ -472,8 +475,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                                 // a pixel outside the image gets an offset the descriptor's range check drops: no branch around the store
                                 const unsigned voff = (unsigned)((gy * W + gx) * ROW + c15e * LB) | ((unsigned)(W - 1 - gx) & OOB6) | (gy < H ? 0u : OOB6);
                                 if (V6_ABL & 8) asm volatile("" :: "v"(o), "v"(voff));
-                                else if constexpr (LB == 16) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, 0, 0);
-                                else __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, 0, 0);
+                                else if constexpr (LB == 16) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, voff, 0, V6_ST_AUX);
+                                else __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, 0, V6_ST_AUX);
                             }
                             if (RES && (FIFO ? r == 0 : r < 2)) res_load(FIFO ? 3 : r + 2);
                             __builtin_amdgcn_sched_barrier(0);

@@ -181,21 +181,29 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         const int x = sx * 32 + r;
         const float* p0 = in0 + (size_t)m * img_stride0;
         const float* p1 = in1 + (size_t)(m / rep1) * img_stride1;
-        // this pixel's 3x3x2 window, split into hi / lo bf16
+        // this pixel's 3x3x2 window, split into hi / lo bf16.  Row tests and row bases are scalar (y is the wave's), the column tests
+        // three per segment: a load costs one add
         __bf16 hi[18], lo[18];
+        bool okx[3];
 #pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
+        for (int dx = 0; dx < 3; ++dx) okx[dx] = (unsigned)(x + dx - 1) < (unsigned)W;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy) {
+            const int gy = y + dy - 1;                          // uniform
+            const bool oky = (unsigned)gy < (unsigned)H;
+            const size_t ro = (size_t)(oky ? gy : 0) * W + (x - 1);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const float* rp = (ci == 0 ? p0 : p1) + ro;
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int gy = y + dy - 1, gx = x + dx - 1;
-                    const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                    const float v = ok ? (ci == 0 ? p0 : p1)[(size_t)gy * W + gx] : 0.f;
+                    const float v = (oky && okx[dx]) ? rp[dx] : 0.f;
                     const __bf16 h = (__bf16)v;
                     hi[ci * 9 + dy * 3 + dx] = h;
                     lo[ci * 9 + dy * 3 + dx] = (__bf16)(v - (float)h);
                 }
+            }
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         for (int i = 0; i < 4; ++i) {
             const int px = 8 * i + (lane >> 3), part = lane & 7;
             const u32x4 v = *(const u32x4*)(stg + px * SROW + part * 16);
-            if (sx * 32 + px < W) *(u32x4*)(orow + (size_t)px * 64 + part * 8) = v;
+            if (sx * 32 + px < W) __builtin_nontemporal_store(v, (u32x4*)(orow + (size_t)px * 64 + part * 8));      // whole lines, read next from HBM
         }
     }
 }
