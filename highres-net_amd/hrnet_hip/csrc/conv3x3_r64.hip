@@ -372,8 +372,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
                 unsigned char* oq = outp + (unsigned)(((2 * tw + pb) * W + (r & ~3)) * 128 + hh * 64 + (r & 3) * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    // whole 128-byte lines, read next by another launch from HBM anyway: non-temporal (A/B: 1.05 -> 0.99 ms; the residual
-                    // variant's 16-byte pieces need the L2 to merge them and lose a third with it)
+                    // whole 128-byte lines, read next by another launch from HBM anyway: non-temporal (A/B: -0.7 %; the residual variant's
+                    // 16-byte pieces need the L2 to merge them: +45 % with nt, and whole-line nt stores there measured no better)
                     if (gy < H && x0 + (r & ~3) + j < W) __builtin_nontemporal_store(uu[j], (u32x4*)(oq + j * 128));
             }
         }
