@@ -15,7 +15,7 @@
 //     OFF phase: start the LDS-DMA (global_load_lds_dwordx4) of the team's next halo tile straight into the team's LDS
 //                buffer - no staging registers, no ds_write; the bank swizzle is applied to each lane's SOURCE address -
 //                then finish the tile just multiplied from the accumulators (bias pre-loaded, PReLU, v_permlane32_swap
-//                so every lane owns 64 contiguous bytes of one pixel, residual, one bf16 rounding, 16-byte stores),
+//                so every lane owns 64 contiguous bytes of one pixel, residual, one bf16 rounding, whole-line stores),
 //                then wait (counted vmcnt: the tile's own stores stay in flight) for the DMAs.
 // One workgroup barrier per phase.  While team A's waves occupy the matrix pipe, team B's waves on the same SIMDs do the
 // VALU / VMEM work, so neither the epilogue nor the input staging costs MFMA time.  No ordinary global load is issued in
@@ -24,9 +24,10 @@
 // Measured in-kernel (profiles/r01_final_inkernel_stamps.txt): ON 5.4 k cycles for 4.6 k of matrix pipe since the fragment
 // reads are hand-issued with counted lgkmcnt waits (multiply()); the OFF phase (6.3 k, 8.2 k with the residual) is bound by
 // the CU's vector-memory pipe - 44 DMA + 32 store (+ 32 residual load) wave-instructions at ~60-70 cycles each.  Without
-// residual, full tiles take their halo from precomputed lane offsets (issue(), fix_borders()) and store whole 128-byte
-// lines through a quad transpose; with the residual neither pays (registers / VALU time) and it runs at 75 % of the
-// achievable HBM bandwidth anyway.
+// residual, full tiles take their halo from precomputed lane offsets (issue(), fix_borders()).  Outputs leave - and the residual
+// arrives - as whole 128-byte lines through a quad transpose, with the non-temporal policy: both are touched once per launch and
+// read / written next by another launch from HBM anyway (round 2: the residual variant too; its own time +2 %, the launches
+// around it -3 %).
 #include <type_traits>
 #include "conv3x3.h"
 
@@ -198,7 +199,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
             b_off[row][kx] = lds0 + (unsigned)(W_BYTES + team * IN_BYTES) + (((unsigned)pix << 7) | ((unsigned)(((pix >> 1) & 7) ^ hh) << 4));
         }
 
-    const unsigned lane_off = (unsigned)((2 * tw * W + r) * 128 + hh * 64);
     f32x16 acc[2][2];                                       // [cout block][pixel row]; lives from the ON phase into the OFF phase
 
     // ---- ON phase: the 36 k-steps of one tile
@@ -288,13 +288,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
             rbase = (const unsigned char*)p.res + ((size_t)ob * p.res_vs + oi) * hw * 128;
             res_alpha = p.alphas ? p.alphas[(size_t)ob * p.alpha_vs + (p.pair_last - oi)] : 1.f;
         }
-        const int gx = x0 + r, gxc = gx < W ? gx : W - 1;
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             const int gy = y0 + 2 * tw + pb, gyc = gy < H ? gy : H - 1;
-            const u32x4* rp = (const u32x4*)(rbase + (unsigned)((gyc * W + gxc) * 128 + hh * 64));
+            // whole 128-byte lines per instruction (lane a of a quad: piece a of the quad's four pixels), transposed back in the
+            // epilogue; read once: non-temporal (with 16-byte pieces per instruction that costs +16 %: nothing merges them)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) resv[pb][g] = rp[g];
+            for (int j = 0; j < 4; ++j) {
+                const int gxj = x0 + (r & ~3) + j, gxjc = gxj < W ? gxj : W - 1;
+                resv[pb][j] = __builtin_nontemporal_load((const u32x4*)(rbase + (unsigned)((gyc * W + gxjc) * 128 + hh * 64 + (r & 3) * 16)));
+            }
         }
     };
 
@@ -310,7 +313,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
         if (p.out_h > 0) { ob = m / p.out_h; oi = m - ob * p.out_h; oimg = (size_t)ob * p.out_vs + oi; }
         // uniform base at the tile origin; per-lane byte offset of (row 2*tw, column r, channel half hh) is tile-independent
         unsigned char* outp = (unsigned char*)p.out + (oimg * hw + (size_t)y0 * W + x0) * 128;
-        const int gx = x0 + r;
         if (RES) {                                          // make the residual's wait happen BEFORE the DMAs are issued
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
@@ -325,8 +327,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             const int gy = y0 + 2 * tw + pb;
-            u32x4* op = (u32x4*)(outp + (unsigned)(pb * W * 128) + lane_off);
-            u32x4 uu[4];                                     // residual-free variant: the row's four pieces, stored together
+            u32x4 uu[4];                                     // the row's four pieces, stored together (whole-line stores)
+            if (RES) quad_transpose(resv[pb], (lane & 1) != 0, (lane & 2) != 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float xa[4], xb[4];                         // channels 8g + 4hh + j of cout block 0 / block 1
@@ -364,16 +366,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_r64_kernel(const ConvParams p)
                     const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pack2_bf16(xa[2], xa[3]), pack2_bf16(xb[2], xb[3]), false, false);
                     u[0] = s0[0]; u[1] = s1[0]; u[2] = s0[1]; u[3] = s1[1];
                 }
-                if (RES) { if (gy < H && gx < W) op[g] = u; }
-                else uu[g] = u;
+                uu[g] = u;
             }
-            if (!RES) {     // whole-line stores (-4 % on the kernel); with the residual the extra VALU work costs more than it saves
+            {   // whole-line stores: the four lanes of a quad exchange their pieces so that each instruction writes whole 128-byte lines
                 quad_transpose(uu, (lane & 1) != 0, (lane & 2) != 0);
                 unsigned char* oq = outp + (unsigned)(((2 * tw + pb) * W + (r & ~3)) * 128 + hh * 64 + (r & 3) * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    // whole 128-byte lines, read next by another launch from HBM anyway: non-temporal (A/B: -0.7 %; the residual variant's
-                    // 16-byte pieces need the L2 to merge them: +45 % with nt, and whole-line nt stores there measured no better)
+                    // read next by another launch, from HBM anyway: non-temporal.  A/B on one box, both variants with whole-line nt
+                    // accesses against plain stores / 16-byte residual pieces: 64->64 1.015 -> 0.986 ms, + residual 1.328 -> 1.356,
+                    // the encoder -0.03 ms and the launches after it a little faster (less of the L2 turned over)
                     if (gy < H && x0 + (r & ~3) + j < W) __builtin_nontemporal_store(uu[j], (u32x4*)(oq + j * 128));
             }
         }

@@ -47,6 +47,9 @@
 #ifndef V6_ST_AUX
 #define V6_ST_AUX 2        // cache policy of the output stores: 2 = nt (the next launch reads them from HBM anyway: A/B -0.5..-1 %)
 #endif
+#ifndef V6_RES_NT
+#define V6_RES_NT 1         // residual loads non-temporal (read once; A/B -0.6 %)
+#endif
 #ifndef V6_BAL
 #define V6_BAL 4          // COUT = 128: eighths of a stage's steps during which waves 4-7 run at raised priority (0 = off; COUT = 64
                           // runs without: A/B on one box, 0.454 vs 0.463 ms)
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
             for (int j = 0; j < 4; ++j)
                 if (!(V6_ABL & 16))
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)res_src(0, j),
-                                                     (lds_ptr6)(smem + GEO::OFF_FIFO + w * GEO::FIFO_WAVE + j * 1024), 16, 0, 0);
+                                                     (lds_ptr6)(smem + GEO::OFF_FIFO + w * GEO::FIFO_WAVE + j * 1024), 16, 0, V6_RES_NT ? 2 : 0);
         };
 
         for (int c = 0; c < 4; ++c) {
@@ -439,7 +442,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if (V6_ABL & 16) { rq[r][j] = lane_row_t{}; rq[r][j][0] = (unsigned)le; }
+#if V6_RES_NT
+                            else rq[r][j] = __builtin_nontemporal_load((const lane_row_t*)res_src(r, j));
+#else
                             else rq[r][j] = *(const lane_row_t*)res_src(r, j);
+#endif
                         }
                     };
                     // rounds 1 and 2 go into the (now dead) fragment registers, round 3 follows when round 0 is done
