@@ -20,6 +20,10 @@
 #define WG_ABL 0        // timing-only ablations of conv_wgrad_kernel (results WRONG): 1 no prefetch of the next tile | 2 no LDS staging | 4 no operand reads
 #endif
 
+// the elementwise passes read every input byte exactly once: non-temporal (they then leave the L2 to the kernels around them)
+#define BWD_LD(p) __builtin_nontemporal_load(p)
+#define BWD_ST(p, v) __builtin_nontemporal_store(v, p)
+
 namespace {
 
 constexpr int RED_BLOCKS = 512;         // partial sums per reduction
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_bias_kernel(const float* __rest
     const size_t stride = (size_t)gridDim.x * RP;
     auto one = [&](size_t r) __attribute__((always_inline)) {
         const size_t o4 = r * C + c4 * 4;
-        const f32x4 d = *(const f32x4*)(dy + o4), v = *(const f32x4*)(src + o4);
+        const f32x4 d = BWD_LD((const f32x4*)(dy + o4)), v = BWD_LD((const f32x4*)(src + o4));
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_finish_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------ elementwise helpers
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
-        ((f32x4*)o)[i] = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+        BWD_ST(((f32x4*)o) + i, BWD_LD(((const f32x4*)a) + i) + BWD_LD(((const f32x4*)b) + i));
 }
 
 // fusion level, forward: s'[b][i] = s[b][i] + alpha[b][partner(i)] * f[b][i]   (or s' = f without the alpha residual)
