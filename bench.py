@@ -343,6 +343,19 @@ def main():
                 extras["c2_fp32"] = {"frames_per_s": round(16 / t, 1), "ms_per_step": round(t * 1e3, 2), "steps": 5,
                                      "workload": "BASELINE configs[1]: B=16, n_views=16, 128x128->384x384, fp32"}
                 step()                                   # leave `sr` holding the timed path's output again
+        if not args.no_extras and ws == 1 and args.precision == "bf16":
+            # BASELINE configs[4]: the same forward on 512 x 512 tiles (16 x the pixels: 3 x 32 GiB of workspace)
+            binding._ws_cache.clear()
+            torch.cuda.empty_cache()
+            l5, a5 = synth_inputs(32, 32, 512, device, seed=500)
+            s5 = torch.empty((32, 1, 1536, 1536), dtype=torch.float32, device=device)
+
+            def c5step():
+                binding.hrnet_forward(packed, dt, 2, True, l5, a5, out=s5)
+            t = timed_local(c5step, 2, 1, device) / 2
+            extras["c5_bf16"] = {"frames_per_s": round(32 / t, 1), "ms_per_step": round(t * 1e3, 1), "steps": 2,
+                                 "workload": "BASELINE configs[4]: B=32, n_views=32, 512x512->1536x1536, bf16"}
+            del l5, a5, s5
         if not args.no_extras and ws == 1:
             binding._ws_cache.clear()
             torch.cuda.empty_cache()
