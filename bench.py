@@ -41,9 +41,11 @@ NETWORK = {   # reference config/config.json:8-34
     "decoder": {"deconv": {"in_channels": 64, "kernel_size": 3, "stride": 3, "out_channels": 64},
                 "final": {"in_channels": 64, "kernel_size": 1, "out_channels": 1}},
 }
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip-level parameters);
+                                                                         # bf16x3: three bf16 MFMAs per product
 PEAK_HBM_GBS = 8000.0
 FUSION_FAMILIES = ("conv3x3_bf16_128x128", "conv3x3_bf16_128x128+res", "conv3x3_bf16_128x64+res", "conv3x3_bf16_128x64")
+TRAFFIC_JSON = "r02_traffic.json"
 KERNEL_SOURCES = ("conv3x3_v6.hip", "conv3x3_r64.hip", "stem.hip", "decoder.hip")
 
 
@@ -90,7 +92,7 @@ def precomputed_traffic(batch, views, size, precision):
     + WRITE_SIZE), committed as profiles/r02_traffic.json together with a hash of the kernel sources they were taken on: stale or
     foreign numbers are not reported."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
         w = tj["workload"]
         if (w["batch"], w["views"], w["size"], w["precision"]) != (batch, views, size, precision):
             return None
@@ -111,11 +113,11 @@ def cpsnr_np(a, b):
     return float((-10.0 * np.log10(np.maximum(cmse, 1e-300))).mean())
 
 
-def cpu_baseline(net_bf16, net_fp32, binding, views, size, budget_s=20.0):
+def cpu_baseline(nets, views, size, budget_s=20.0):
     """Time the torch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload, and check both HIP paths against
     its output on that very sample (the oracle as the checker, never as the thing measured on the GPU side)."""
     from oracle import torch_port
-    st = {k: v.detach().float().cpu() for k, v in net_fp32.state_dict().items()}
+    st = {k: v.detach().float().cpu() for k, v in nets["fp32"].state_dict().items()}
     threads = torch.get_num_threads()
     lrs, alphas = synth_inputs(1, views, size, "cpu", 5)
     t0 = time.perf_counter()
@@ -131,7 +133,7 @@ def cpu_baseline(net_bf16, net_fp32, binding, views, size, budget_s=20.0):
                      f"of HRNet.forward (oracle/torch_port.py), {threads} threads, {dt:.1f} s"}
     parity = {}
     with torch.no_grad():
-        for name, net in (("bf16", net_bf16), ("fp32", net_fp32)):
+        for name, net in nets.items():
             got = net(lrs.cuda(), alphas.cuda()).cpu().numpy()
             import numpy as np
             parity[name] = {"max_rel": float(np.abs(got - want).max() / np.abs(want).max()), "cpsnr_db": round(cpsnr_np(got, want), 2)}
@@ -205,6 +207,105 @@ def make_train_step(device, batch, views, patch, overlap=True):
     return step
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` launched directly (no torchrun environment): start N fresh child processes - one rank per GPU,
+    rendezvous on 127.0.0.1 - BEFORE this process makes any GPU call (it never does: `torch.cuda.device_count()` does not
+    initialise the device on this image), pass rank 0's stdout through and fail if any child fails.  Never an exec of a process
+    that has touched the GPU."""
+    import subprocess
+    rehearsal = os.environ.get("HRN_DIST_BACKEND") == "gloo" and torch.cuda.device_count() == 0
+    if not rehearsal and "HRN_BENCH_DEVICE" not in os.environ and torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} ROCm device(s) visible - refusing to run fewer ranks than "
+                         f"asked for (HRN_BENCH_DEVICE=<id> rehearses N ranks on one card; HRN_DIST_BACKEND=gloo on a box without a GPU "
+                         f"rehearses the launcher alone)")
+    import tempfile
+    port = _free_port()
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for rank in range(n):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if rank == 0 else subprocess.DEVNULL))
+        # wait for all of them; a rank that dies takes the others with it (they would sit in a collective until its timeout)
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            if any(c not in (None, 0) for c in codes):
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                codes = [p.wait() for p in procs]
+                break
+            time.sleep(0.1)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode("utf-8", "replace"))
+        sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py --gpus {n}: rank exit codes {codes}")
+
+
+def ranks_seen(rank, ws, device):
+    """Every rank's id as rank 0 sees them after an all_gather (proof that N processes took part), and the backend's name."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return [0], None
+    t = torch.tensor([rank], dtype=torch.int64, device=device)
+    got = [torch.zeros_like(t) for _ in range(ws)]
+    dist.all_gather(got, t)
+    return sorted(int(g.item()) for g in got), dist.get_backend()
+
+
+def rehearse_plumbing(args, rank, ws, hdist):
+    """No ROCm device + HRN_DIST_BACKEND=gloo: the launcher / rendezvous / barrier / max-over-ranks plumbing of the N-rank run on CPU
+    stand-in steps (tests/test_dist_cpu.py::test_bench_spawns_its_own_ranks).  No kernel runs, `value` is null: never a measurement."""
+    cpu = torch.device("cpu")
+    seen, backend = ranks_seen(rank, ws, cpu)
+    elapsed = timed_cpu(lambda: time.sleep(0.001), args.steps, args.warmup, hdist)
+    if rank == 0:
+        print(json.dumps({"metric": "SR frames/sec (384x384 out) at B=32, n_views=32", "value": None, "unit": "SR frames/s", "n_gpus": ws,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None,
+                          "data": "none: launcher rehearsal on CPU stand-in steps, no kernel ran", "rehearsal": True,
+                          "ranks_seen": seen, "backend": backend, "mode": args.mode,
+                          "config": {"workload": "plumbing only", "global_batch": args.batch * ws, "parallelism": f"dp{ws}"}}), flush=True)
+    hdist.finalize()
+
+
+def timed_cpu(step, steps, warmup, hdist):
+    for _ in range(warmup):
+        step()
+    hdist.barrier(None)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    hdist.barrier(None)
+    return hdist.max_over_ranks(time.perf_counter() - t0, None)
+
+
+def extra(extras, key, fn):
+    """One extra measurement: whatever goes wrong in it (an OOM on a box with less free HBM, ...) is recorded under its key and never
+    costs the contract line."""
+    try:
+        extras[key] = fn()
+    except Exception as e:                                     # noqa: BLE001 - the headline must survive any extra
+        extras[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            torch.cuda.synchronize()
+        except Exception:                                      # noqa: BLE001
+            pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,22 +316,33 @@ def main():
     ap.add_argument("--views", type=int, default=32)
     ap.add_argument("--size", type=int, default=128, help="LR side (forward mode)")
     ap.add_argument("--patch", type=int, default=64, help="LR patch side (train mode; config.json patch_size)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--profile-steps", type=int, default=3, help="extra instrumented steps for the rooflines (not in `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / config-2 / train-step extra measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / bf16x3 / config-2 / config-5 / train-step extra measurements")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    from hrnet_hip import binding, dist as hdist
-    from DeepNetworks.HRNet import HRNet
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                     # the driver's form of the command: this process only launches and collects
+        return
 
+    from hrnet_hip import dist as hdist
     rank, local_rank, ws = hdist.init()            # joins the process group BEFORE any GPU call of this process
-    if ws != args.gpus and ws > 1:
+    if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {ws}")
     if not torch.cuda.is_available():
+        if os.environ.get("HRN_DIST_BACKEND") == "gloo":
+            return rehearse_plumbing(args, rank, ws, hdist)
         raise SystemExit("bench.py needs a ROCm device: the HIP path has no CPU fallback")
+    from hrnet_hip import binding
+    from DeepNetworks.HRNet import HRNet
     device = torch.device("cuda", int(os.environ.get("HRN_BENCH_DEVICE", local_rank if ws > 1 else 0)))   # override: rehearsal of N ranks on one GPU
     torch.cuda.set_device(device)
+    seen, backend = ranks_seen(rank, ws, device)
+    if len(seen) != ws:
+        raise SystemExit(f"all_gather saw ranks {seen}, expected {ws}")
 
     if args.mode == "train":
         step = make_train_step(device, args.batch, args.views, args.patch)
@@ -245,10 +357,11 @@ def main():
                 "ms_per_step": round(elapsed / steps * 1e3, 2), "ms_per_step_without_exchange": round(no_x / steps * 1e3, 2),
                 "early_slice_launched_during_backward": bool(step.early) if ws > 1 else None,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "ranks_seen": seen, "backend": backend,
                 "config": {"workload": f"train.py:164-191 on the HIP modules: HRNet + ShiftNet + Lanczos + registered cPSNR loss + FusedAdam, "
                                        f"B={args.batch}/GPU, n_views={args.views}, {args.patch}x{args.patch} patches (BASELINE configs[3])",
                            "global_batch": args.batch * ws,
-                           "parallelism": f"dp{ws}: {os.environ.get('HRN_DIST_BACKEND', 'RCCL')} all-reduce of 139 MB of fp32 gradients per step, ShiftNet's slice overlapped with HRNet's backward",
+                           "parallelism": f"dp{ws}: {backend or 'no'} all-reduce of 139 MB of fp32 gradients per step, ShiftNet's slice overlapped with HRNet's backward",
                            "weights": "random init (seed 1234), fc2 ~ N(0, 1e-3)"}}), flush=True)
         hdist.finalize()
         return
@@ -256,138 +369,230 @@ def main():
     torch.manual_seed(1234)                               # same random-init weights on every rank
     net = HRNet(dict(NETWORK, precision=args.precision)).to(device).eval()
     lrs, alphas = synth_inputs(args.batch, args.views, args.size, device, seed=100 + rank)
-    sr = torch.empty((args.batch, 1, 3 * args.size, 3 * args.size), dtype=torch.float32, device=device)
-    packed, dt = net.packed_parameters()
+
+    sr_holder = [None]
 
     def step():
-        binding.hrnet_forward(packed, dt, 2, True, lrs, alphas, out=sr)
+        sr_holder[0] = net(lrs, alphas)                    # the module call the reference's callers make (predict.py:39, train.py:205)
 
     with torch.no_grad():
         elapsed = timed(step, args.steps, args.warmup, device, hdist)
     frames = args.batch * args.steps * ws
     value = frames / elapsed
+    if rank != 0:
+        hdist.finalize()
+        return
 
-    roofline, roofline_hbm, kernels, parity, extras = None, None, {}, {}, {}
-    if rank == 0:
-        # instrumented steps: hipEvent pair around every kernel launch, on the launch stream (torch's current stream)
-        binding.profile_enable(True)
+    storage = {"bf16": "bf16 storage + fp32 accumulate", "fp32": "fp32 storage, exact-fp32 MFMA",
+               "bf16x3": "fp32 values as bf16 hi+lo pairs, 3 bf16 MFMAs per product, fp32 accumulate"}[args.precision]
+    tf = flops_per_frame(args.views, args.size) * value / 1e12
+    line = {
+        "metric": "SR frames/sec (384x384 out) at B=32, n_views=32", "value": round(value, 2), "unit": "SR frames/s",
+        "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic", "ranks_seen": seen, "backend": backend,
+        "config": {"workload": f"HRNet.forward B={args.batch}/GPU, n_views={args.views}, {args.size}x{args.size}->"
+                               f"{3 * args.size}x{3 * args.size}, {storage} (BASELINE configs[2])",
+                   "timed_call": "DeepNetworks.HRNet.HRNet.__call__ in eval mode -> torch.ops.hrnet_hip.hrnet_forward -> hrn_hrnet_forward (C ABI)",
+                   "global_batch": args.batch * ws, "parallelism": f"dp{ws} replicas, no data-path collective",
+                   "weights": "random init (torch default, seed 1234)"},
+        "whole_forward_tflops": round(tf, 1),
+        "roofline": None, "roofline_hbm": None, "parity": {}, "cpu_baseline": None, "kernels": {},
+    }
+    try:
         with torch.no_grad():
-            for _ in range(max(1, args.profile_steps)):
-                step()
-        torch.cuda.synchronize(device)
-        binding.profile_enable(False)
-        prof = binding.profile_read()
-        nprof = max(1, args.profile_steps)
-        total_ms = sum(v["ms"] for v in prof.values()) or 1.0
-        for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
-            avg = v["ms"] / max(v["launches"], 1)
-            kernels[name] = {"launches_per_step": v["launches"] // nprof, "avg_ms": round(avg, 4),
-                             "share": round(v["ms"] / total_ms, 4),
-                             "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] > 0 else None,
-                             "gbs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] > 0 else None}
-        name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        achieved = v["flops"] / v["ms"] / 1e9            # TFLOP/s: algorithmic FLOPs of the launches / their summed duration
-        peak = PEAK_TFLOPS[args.precision]
-        tj = precomputed_traffic(args.batch, args.views, args.size, args.precision)
-        traffic = tj["bytes_per_launch"].get(name) if tj else None
-        roofline = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_source": "precomputed: profiles/r02_traffic.json (rocprofv3 --pmc passes of tools/prof_all.sh on these kernel sources)" if traffic else None,
-                    "bytes_per_launch_algorithmic": v["bytes"] / max(v["launches"], 1),
-                    "launches": v["launches"], "avg_launch_ms": round(v["ms"] / max(v["launches"], 1), 4),
-                    "flops_per_launch": v["flops"] / max(v["launches"], 1),
-                    "algorithmic_gbs": round(v["bytes"] / v["ms"] / 1e6, 1)}
-        # the recursive fusion as ONE operator against the HBM roof (north_star): SURVEY 8d's algorithmic bytes = units of
-        # 64*HW*es (2h read + h write per level) per sample; measured time = all its conv launches of the instrumented steps
-        fus = [prof[f] for f in FUSION_FAMILIES if f in prof]
-        if fus and args.precision == "bf16":
-            fus_ms = sum(f["ms"] for f in fus) / nprof
-            alg = fusion_units(args.views) * 64 * args.size * args.size * 2 * args.batch
-            layer_bytes = sum(f["bytes"] for f in fus) / nprof
-            ctr = sum(tj["bytes_per_launch"].get(k, 0) * kernels[k]["launches_per_step"] for k in FUSION_FAMILIES if tj and k in kernels) if tj else None
-            roofline_hbm = {"stage": "recursive fusion (all levels of one forward)", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
-                            "achieved": round(alg / fus_ms / 1e6, 1), "frac": round(alg / fus_ms / 1e6 / PEAK_HBM_GBS, 4),
-                            "algorithmic_bytes": alg, "ms": round(fus_ms, 3),
-                            "per_layer_algorithmic_bytes": layer_bytes, "per_layer_algorithmic_gbs": round(layer_bytes / fus_ms / 1e6, 1),
-                            "traffic": ctr, "traffic_gbs": round(ctr / fus_ms / 1e6, 1) if ctr else None,
-                            "note": "the stage is MFMA-bound (~1000 FLOP/B): its HBM fraction states how far the conv-per-launch "
-                                    "decomposition is from the fused operator's minimal traffic, not a saturated memory system"}
+            measure_rank0(args, ws, device, net, lrs, alphas, step, sr_holder, binding, line)
+    except Exception as e:                                     # noqa: BLE001 - the contract line is printed whatever the diagnostics do
+        line["diagnostics_error"] = f"{type(e).__name__}: {e}"[:400]
+    finally:
+        print(json.dumps(line), flush=True)
+    hdist.finalize()
 
-        # ---- parity of the run that was timed: bf16 output vs the exact-fp32 HIP path on the same batch (cPSNR: Evaluator.py:34-38, all-ones mask)
-        with torch.no_grad():
-            other = "fp32" if args.precision == "bf16" else "bf16"
-            net.precision = other
-            p2, d2 = net.packed_parameters()
-            ref = binding.hrnet_forward(p2, d2, 2, True, lrs, alphas)
-            net.precision = args.precision
-            a, b = (sr, ref) if args.precision == "bf16" else (ref, sr)                 # a: bf16, b: fp32
-            ones = torch.ones_like(a[:, 0])
-            parity["bf16_vs_fp32_hip_path"] = {
-                "max_rel": float((a - b).abs().max() / b.abs().max()),
-                "cpsnr_db": round(float(binding.get_loss(a[:, 0], b[:, 0], ones, "cPSNR").mean()), 2),
+
+def profile_families(binding, device, fn, n=1):
+    """Run fn() n times with the library's hipEvent profiler on; -> {family: {launches, ms, flops, bytes}} summed over the n runs."""
+    binding.profile_enable(True)
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(device)
+    binding.profile_enable(False)
+    return binding.profile_read()
+
+
+def measure_rank0(args, ws, device, net, lrs, alphas, step, sr_holder, binding, line):
+    """Everything of the line beyond the contract keys (rank 0, after the timed region): rooflines, parity, extras, CPU baseline."""
+    from DeepNetworks.HRNet import HRNet
+    nprof = max(1, args.profile_steps)
+    prof = profile_families(binding, device, step, nprof)
+    sr = sr_holder[0]
+    kernels = line["kernels"]
+    total_ms = sum(v["ms"] for v in prof.values()) or 1.0
+    for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+        avg = v["ms"] / max(v["launches"], 1)
+        kernels[name] = {"launches_per_step": v["launches"] // nprof, "avg_ms": round(avg, 4),
+                         "share": round(v["ms"] / total_ms, 4),
+                         "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] > 0 else None,
+                         "gbs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] > 0 else None}
+    name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    achieved = v["flops"] / v["ms"] / 1e9            # TFLOP/s: algorithmic FLOPs of the launches / their summed duration
+    peak = PEAK_TFLOPS[args.precision]
+    tj = precomputed_traffic(args.batch, args.views, args.size, args.precision)
+    traffic = tj["bytes_per_launch"].get(name) if tj else None
+    line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "traffic_source": f"precomputed: profiles/{TRAFFIC_JSON} (rocprofv3 --pmc passes of tools/prof_all.sh on these kernel sources)" if traffic else None,
+                        "bytes_per_launch_algorithmic": v["bytes"] / max(v["launches"], 1),
+                        "launches": v["launches"], "avg_launch_ms": round(v["ms"] / max(v["launches"], 1), 4),
+                        "flops_per_launch": v["flops"] / max(v["launches"], 1),
+                        "algorithmic_gbs": round(v["bytes"] / v["ms"] / 1e6, 1)}
+    if args.precision == "bf16x3":
+        line["roofline"]["note"] = "peak = the bf16 MFMA peak / 3: every product costs three bf16 MFMAs (hi*hi + hi*lo + lo*hi)"
+    # the recursive fusion as ONE operator against the HBM roof (north_star): SURVEY 8d's algorithmic bytes = units of
+    # 64*HW*es (2h read + h write per level) per sample; measured time = all its conv launches of the instrumented steps
+    fus = [prof[f] for f in FUSION_FAMILIES if f in prof]
+    if fus and args.precision == "bf16":
+        fus_ms = sum(f["ms"] for f in fus) / nprof
+        alg = fusion_units(args.views) * 64 * args.size * args.size * 2 * args.batch
+        layer_bytes = sum(f["bytes"] for f in fus) / nprof
+        ctr = sum(tj["bytes_per_launch"].get(k, 0) * kernels[k]["launches_per_step"] for k in FUSION_FAMILIES if tj and k in kernels) if tj else None
+        line["roofline_hbm"] = {"stage": "recursive fusion (all levels of one forward)", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                                "achieved": round(alg / fus_ms / 1e6, 1), "frac": round(alg / fus_ms / 1e6 / PEAK_HBM_GBS, 4),
+                                "algorithmic_bytes": alg, "ms": round(fus_ms, 3),
+                                "per_layer_algorithmic_bytes": layer_bytes, "per_layer_algorithmic_gbs": round(layer_bytes / fus_ms / 1e6, 1),
+                                "traffic": ctr, "traffic_gbs": round(ctr / fus_ms / 1e6, 1) if ctr else None,
+                                "note": "the stage is MFMA-bound (~1000 FLOP/B): its HBM fraction states how far the conv-per-launch "
+                                        "decomposition is from the fused operator's minimal traffic, not a saturated memory system"}
+    enc = [prof[f] for f in prof if f.startswith("conv3x3_") and "_64x64" in f]
+    if enc:
+        ems, efl = sum(f["ms"] for f in enc), sum(f["flops"] for f in enc)
+        line["roofline_encoder"] = {"stage": "encoder 64->64 convs (north_star: >= 0.70 of the MFMA roof)", "bound": "mfma", "unit": "TFLOP/s",
+                                    "achieved": round(efl / ems / 1e9, 1), "peak": peak, "frac": round(efl / ems / 1e9 / peak, 4),
+                                    "ms": round(ems / nprof, 3)}
+
+    # ---- parity of the run that was timed: against the exact-fp32 HIP path on the same batch (cPSNR: Evaluator.py:34-38, all-ones mask)
+    parity, extras = line["parity"], {}
+    nets = {args.precision: net}
+
+    def other_net(prec):
+        if prec not in nets:
+            n2 = HRNet(dict(NETWORK, precision=prec)).to(device).eval()
+            n2.load_state_dict(net.state_dict())
+            nets[prec] = n2
+        return nets[prec]
+
+    ref32 = sr if args.precision == "fp32" else other_net("fp32")(lrs, alphas)
+    ones = torch.ones_like(sr[:, 0])
+
+    def vs_fp32(x):
+        return {"max_rel": float((x - ref32).abs().max() / ref32.abs().max()),
+                "cpsnr_db": round(float(binding.get_loss(x[:, 0], ref32[:, 0], ones, "cPSNR").mean()), 2),
                 "batch": f"the timed batch (B={args.batch}, n_views={args.views})"}
-            if not args.no_extras and ws == 1:             # (multi-rank runs keep rank 0's tail short: the other ranks are already done)
-                # the exact-fp32 path at the metric's shape (the path that meets the 1e-3 contract) and BASELINE configs[1]
-                def fstep():
-                    binding.hrnet_forward(p2 if other == "fp32" else packed, binding.F32, 2, True, lrs, alphas, out=sr)
-                t = timed_local(fstep, 3, 1, device) / 3
-                extras["fp32_path"] = {"frames_per_s": round(args.batch / t, 1), "ms_per_step": round(t * 1e3, 2), "steps": 3,
-                                       "workload": f"B={args.batch}, n_views={args.views}, exact-fp32 MFMA"}
-                l2, a2 = synth_inputs(16, 16, 128, device, seed=300)
-                s2 = torch.empty((16, 1, 384, 384), dtype=torch.float32, device=device)
-                pf = p2 if other == "fp32" else packed
+    if args.precision != "fp32":
+        parity[f"{args.precision}_vs_fp32_hip_path"] = vs_fp32(sr)
+    else:
+        parity["bf16_vs_fp32_hip_path"] = vs_fp32(other_net("bf16")(lrs, alphas))
 
-                def c2step():
-                    binding.hrnet_forward(pf, binding.F32, 2, True, l2, a2, out=s2)
-                t = timed_local(c2step, 5, 2, device) / 5
-                extras["c2_fp32"] = {"frames_per_s": round(16 / t, 1), "ms_per_step": round(t * 1e3, 2), "steps": 5,
-                                     "workload": "BASELINE configs[1]: B=16, n_views=16, 128x128->384x384, fp32"}
-                step()                                   # leave `sr` holding the timed path's output again
-        if not args.no_extras and ws == 1 and args.precision == "bf16":
-            # BASELINE configs[4]: the same forward on 512 x 512 tiles (16 x the pixels: 3 x 32 GiB of workspace)
-            binding._ws_cache.clear()
-            torch.cuda.empty_cache()
-            l5, a5 = synth_inputs(32, 32, 512, device, seed=500)
-            s5 = torch.empty((32, 1, 1536, 1536), dtype=torch.float32, device=device)
+    if not args.no_extras and ws == 1:             # (multi-rank runs keep rank 0's tail short: the other ranks are already done)
+        def path_extra(prec, fam, steps):
+            n2 = other_net(prec)
+            out = [None]
 
-            def c5step():
-                binding.hrnet_forward(packed, dt, 2, True, l5, a5, out=s5)
-            t = timed_local(c5step, 2, 1, device) / 2
-            extras["c5_bf16"] = {"frames_per_s": round(32 / t, 1), "ms_per_step": round(t * 1e3, 1), "steps": 2,
-                                 "workload": "BASELINE configs[4]: B=32, n_views=32, 512x512->1536x1536, bf16"}
-            del l5, a5, s5
-        if not args.no_extras and ws == 1:
+            def f():
+                out[0] = n2(lrs, alphas)
+            t = timed_local(f, steps, 1, device) / steps
+            pf = profile_families(binding, device, f, 1)
+            r = {"frames_per_s": round(args.batch / t, 1), "ms_per_step": round(t * 1e3, 2), "steps": steps,
+                 "workload": f"B={args.batch}, n_views={args.views}, precision={prec}"}
+            if prec != "fp32":
+                r["parity_vs_fp32_hip_path"] = vs_fp32(out[0])
+            if fam in pf and pf[fam]["ms"] > 0:
+                a = pf[fam]["flops"] / pf[fam]["ms"] / 1e9
+                r["roofline"] = {"kernel": fam, "bound": "mfma", "achieved": round(a, 2), "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                                 "frac": round(a / PEAK_TFLOPS[prec], 4), "avg_launch_ms": round(pf[fam]["ms"] / pf[fam]["launches"], 4)}
+            tot = sum(v["flops"] for v in pf.values()) / max(sum(v["ms"] for v in pf.values()), 1e-9) / 1e9
+            r["whole_forward_tflops"] = round(tot, 1)
+            return r
+        if args.precision != "fp32":        # the exact-fp32 path at the metric's shape (the path that meets the 1e-3 contract bit for bit)
+            extra(extras, "fp32_path", lambda: path_extra("fp32", "conv3x3_f32_128x128", 3))
+        if args.precision != "bf16x3" and binding.has_bf16x3():
+            extra(extras, "bf16x3_path", lambda: path_extra("bf16x3", "conv3x3_bf16x3_128x128+res", 5))
+
+        def c2():
+            l2, a2 = synth_inputs(16, 16, 128, device, seed=300)
+            n32 = other_net("fp32")
+            t = timed_local(lambda: n32(l2, a2), 5, 2, device) / 5
+            return {"frames_per_s": round(16 / t, 1), "ms_per_step": round(t * 1e3, 2), "steps": 5,
+                    "workload": "BASELINE configs[1]: B=16, n_views=16, 128x128->384x384, fp32"}
+        extra(extras, "c2_fp32", c2)
+
+        def lanczos_roof():
+            img = torch.rand((1, args.batch, 3 * args.size, 3 * args.size), device=device)
+            sh = (torch.rand((args.batch, 2), device=device) - 0.5) * 2
+            f = lambda: binding.lanczos_shift(img, sh)         # noqa: E731
+            timed_local(f, 3, 2, device)
+            pf = profile_families(binding, device, f, 10)["lanczos_shift"]
+            gbs = pf["bytes"] / pf["ms"] / 1e6
+            return {"kernel": "lanczos_shift", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(pf["ms"] / pf["launches"], 4),
+                    "algorithmic_bytes_per_launch": pf["bytes"] / pf["launches"],
+                    "workload": f"lanczos_shift of {args.batch} images of {3 * args.size}x{3 * args.size} (one launch; SURVEY 8d: 2*B*9HW*4 B)"}
+        extra(extras, "roofline_lanczos", lanczos_roof)
+
+        def shiftnet_fwd():
+            from DeepNetworks.ShiftNet import ShiftNet
+            sn = ShiftNet().to(device).eval()
+            x = torch.rand((args.batch, 2, 128, 128), device=device)
+            f = lambda: sn(x)                                   # noqa: E731
+            t = timed_local(f, 5, 2, device) / 5
+            pf = profile_families(binding, device, f, 3)
+            r = {"ms": round(t * 1e3, 3), "workload": f"ShiftNet.forward (eval), B={args.batch} pairs of 128x128",
+                 "kernels": {k: {"avg_ms": round(v["ms"] / v["launches"], 4), "launches_per_forward": v["launches"] // 3,
+                                 "tflops": round(v["flops"] / v["ms"] / 1e9, 2), "gbs": round(v["bytes"] / v["ms"] / 1e6, 1)}
+                             for k, v in sorted(pf.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}}
+            if "fc1" in pf:
+                g = pf["fc1"]["bytes"] / pf["fc1"]["ms"] / 1e6
+                r["fc1_roofline"] = {"bound": "hbm", "achieved": round(g, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(g / PEAK_HBM_GBS, 4),
+                                     "note": "one read of the 134 MB weight matrix per forward"}
+            return r
+        extra(extras, "shiftnet_forward", shiftnet_fwd)
+        step()                                   # leave the timed path's output the most recent one again
+
+        if args.precision == "bf16":
+            def c5():
+                # BASELINE configs[4]: the same forward on 512 x 512 tiles (16 x the pixels: 3 x 32 GiB of workspace)
+                binding._ws_cache.clear()
+                torch.cuda.empty_cache()
+                free, _ = torch.cuda.mem_get_info(device)
+                if free < 120 * (1 << 30):
+                    return {"skipped": f"only {free / (1 << 30):.0f} GiB of HBM free; the 512x512 forward needs ~100 GiB of workspace"}
+                l5, a5 = synth_inputs(32, 32, 512, device, seed=500)
+                try:
+                    t = timed_local(lambda: net(l5, a5), 2, 1, device) / 2
+                finally:
+                    del l5, a5
+                    binding._ws_cache.clear()
+                    torch.cuda.empty_cache()
+                return {"frames_per_s": round(32 / t, 1), "ms_per_step": round(t * 1e3, 1), "steps": 2,
+                        "workload": "BASELINE configs[4]: B=32, n_views=32, 512x512->1536x1536, bf16"}
+            extra(extras, "c5_bf16", c5)
+
+        def train():
             binding._ws_cache.clear()
             torch.cuda.empty_cache()
             tstep = make_train_step(device, 32, 32, 64)
             t = timed_local(tstep, 3, 2, device) / 3
-            extras["train_step"] = {"ms_per_step": round(t * 1e3, 1), "samples_per_s": round(32 / t, 1), "steps": 3,
-                                    "workload": "src/train.py:164-191 on the HIP modules, B=32, n_views=32, 64x64 patches, fp32 (python bench.py --mode train)"}
+            return {"ms_per_step": round(t * 1e3, 1), "samples_per_s": round(32 / t, 1), "steps": 3,
+                    "workload": "src/train.py:164-191 on the HIP modules, B=32, n_views=32, 64x64 patches, fp32 (python bench.py --mode train)"}
+        extra(extras, "train_step", train)
+    line.update(extras)
 
-    cpu = None
-    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
-        net32 = HRNet(dict(NETWORK, precision="fp32")).to(device).eval()
-        net32.load_state_dict(net.state_dict())
-        cpu, vs_port = cpu_baseline(net, net32, binding, args.views, args.size)
+    if ws == 1 and not args.no_cpu_baseline:
+        binding._ws_cache.clear()
+        torch.cuda.empty_cache()
+        cpu, vs_port = cpu_baseline({p: other_net(p) for p in (["bf16", "fp32"] + (["bf16x3"] if binding.has_bf16x3() else []))},
+                                    args.views, args.size)
+        line["cpu_baseline"] = cpu
         parity["vs_cpu_port_on_cpu_baseline_sample"] = vs_port
-
-    if rank == 0:
-        tf = flops_per_frame(args.views, args.size) * value / 1e12
-        line = {
-            "metric": "SR frames/sec (384x384 out) at B=32, n_views=32", "value": round(value, 2), "unit": "SR frames/s",
-            "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"HRNet.forward B={args.batch}/GPU, n_views={args.views}, {args.size}x{args.size}->"
-                                   f"{3 * args.size}x{3 * args.size}, {args.precision} storage + fp32 accumulate (BASELINE configs[2])",
-                       "global_batch": args.batch * ws, "parallelism": f"dp{ws} replicas, no data-path collective",
-                       "weights": "random init (torch default, seed 1234)"},
-            "whole_forward_tflops": round(tf, 1),
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "parity": parity, "cpu_baseline": cpu, "kernels": kernels,
-        }
-        line.update(extras)
-        print(json.dumps(line), flush=True)
-    hdist.finalize()
 
 
 if __name__ == "__main__":

@@ -111,13 +111,24 @@ class _HRNetLazyTrainFunction(torch.autograd.Function):
     def forward(ctx, module, names, lrs, alphas, *params):
         packed, dt = module.packed_parameters()
         ctx.module, ctx.names = module, names
+        ctx.versions = tuple(p._version for p in params)
         ctx.save_for_backward(lrs, alphas, *params)
         return binding.hrnet_forward(packed, dt, module._num_layers, module.fuse.alpha_residual, lrs, alphas)
+
+    _warned = False
 
     @staticmethod
     def backward(ctx, d_sr):
         lrs, alphas, *params = ctx.saved_tensors
         m = ctx.module
+        if not _HRNetLazyTrainFunction._warned:
+            _HRNetLazyTrainFunction._warned = True
+            import warnings
+            warnings.warn("HRNet(precision='bf16').train(): the forward ran the bf16 inference kernels, this backward recomputes "
+                          "the forward on the fp32 training kernels and returns the fp32 model's gradients (two forwards per step, "
+                          "loss and gradient ~1e-2 apart). Train with precision='fp32' or 'bf16x3'.", RuntimeWarning, stacklevel=2)
+        if tuple(p._version for p in params) != ctx.versions:
+            raise RuntimeError("HRNet bf16 train-mode backward: a parameter was modified between forward and backward")
         packed = m._packed_f32()
         _, tws = binding.hrnet_forward_train(packed, lrs, alphas, m._num_layers, m.fuse.alpha_residual)
         named = dict(zip(ctx.names, params))

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HRNET_HIP_LIB") or os.path.join(_HERE, "libhrnet_hip.so")   # override: A/B-testing a build
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 MAX_RES_LAYERS = 8
 _DT_TORCH = {F32: torch.float32, BF16: torch.bfloat16}
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -121,6 +121,11 @@ def load_library():
 
 class HrnetHipError(RuntimeError):
     pass
+
+
+def has_bf16x3():
+    """True when the loaded library implements the split-bf16 precision mode (HRN_DTYPE_BF16X3)."""
+    return load_library().hrn_hrnet_packed_bytes(BF16X3, 2) != 0
 
 
 def _check(rc, what):

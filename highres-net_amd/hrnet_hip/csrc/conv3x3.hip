@@ -29,7 +29,6 @@
 #include "conv3x3.h"
 #include <stdlib.h>
 
-int hrn_launch_conv3x3_v3(int cin, int cout, const ConvParams& p, hipStream_t stream);   // conv3x3_v3.hip
 
 namespace {
 
@@ -363,15 +362,14 @@ int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream
     HRN_CHECK(p.res_mode != 2 || (p.pair_h > 0 && p.stack && cout == 128), -2, "conv3x3: res_mode 2 needs a pair descriptor and cout=128");
     HRN_CHECK(p.in_pair || p.in, -2, "conv3x3: null input");
     HRN_CHECK(p.res_mode != 3 || p.out_h > 0, -2, "conv3x3: res_mode 3 needs slot output");
-    if (dt == HRN_BF16) {
-        // bf16 layers run on the wave-specialised kernel (conv3x3_v3.hip); HRN_CONV_V3=0 selects the symmetric kernel of
-        // this file for A/B timing (both are parity-tested).  f32 (exact-fp32 MFMA, already 84 % of its peak) stays here.
-        static int use_v3 = -1;
-        if (use_v3 < 0) { const char* e = getenv("HRN_CONV_V3"); use_v3 = e ? atoi(e) : 1; }
-        if (use_v3) {
-            const int rc = hrn_launch_conv3x3_v3(cin, cout, p, stream);
-            if (rc != -100) return rc;
-        }
+    if (dt == HRN_BF16 && !p.scale && !p.relu) {
+        // the HRNet layers in bf16: resident-weights kernel (conv3x3_r64.hip) for the encoder's 64 -> 64 layers, conv3x3_v6.hip for the
+        // three layers of a fusion level.  What they decline (images beyond their 32-bit in-image offsets, > 8.3 Mpixel) runs on this
+        // file's general kernel; HRN_CONV_R64=0 / HRN_CONV_V6=0 force that route (A/B timing, and the test that covers it).
+        static const int r64 = [] { const char* e = getenv("HRN_CONV_R64"); return e ? atoi(e) : 1; }();
+        static const int v6 = [] { const char* e = getenv("HRN_CONV_V6"); return e ? atoi(e) : 1; }();
+        if (cin == 64 && cout == 64 && r64) { const int rc = hrn_launch_conv3x3_r64(p, stream); if (rc != -100) return rc; }
+        if (cin == 128 && v6) { const int rc = hrn_launch_conv3x3_v6(cout, p, stream); if (rc != -100) return rc; }
     }
 #define HRN_CONV_CASE(DT_, CI_, CO_) if (dt == DT_ && cin == CI_ && cout == CO_) return launch<DT_, CI_, CO_>(p, stream);
     HRN_CONV_CASE(HRN_BF16, 64, 64)

@@ -126,6 +126,7 @@ class GradBuckets:
     world size.  Without a process group everything is the identity.  Works on any device (the CPU tests drive it on gloo)."""
 
     def __init__(self, flat, params, early=()):
+        import weakref
         self.flat, self.params = flat, list(params)
         early = list(early)
         ids = {id(p): i for i, p in enumerate(self.params)}
@@ -135,27 +136,64 @@ class GradBuckets:
             off += p.numel()
         self.n = off
         self.lo = self.hi = 0
+        self._early = early
         self._early_n = len(early)
+        self._handles = []
         if early:
             idx = sorted(ids[id(p)] for p in early)
             if idx != list(range(idx[0], idx[0] + len(idx))):
                 raise ValueError("GradBuckets: the early parameters must be consecutive in the flat buffer")
             self.lo, self.hi = offs[idx[0]], offs[idx[-1]] + self.params[idx[-1]].numel()
+            ref = weakref.ref(self)            # the hook must not keep a replaced bucket (and its 139 MB buffer) alive
+
+            def hook(param, ref=ref):
+                me = ref()
+                if me is not None:
+                    me._arrived(param)
             for p in early:
-                p.register_post_accumulate_grad_hook(self._arrived)
-        self._count, self._work, self.early_launched_in_backward = 0, [], False
+                self._handles.append(p.register_post_accumulate_grad_hook(hook))
+        self._count, self._work, self.early_launched_in_backward, self._reduced = 0, [], False, False
         self.enabled = True                 # False: a step without the exchange (bench.py's "without exchange" leg)
+
+    def close(self):
+        """Remove the backward hooks (a rebuilt optimiser registers its own; stale ones would reduce a dead buffer)."""
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                   # noqa: BLE001 - interpreter shutdown
+            pass
 
     def begin(self):
         """Start of a step (optimizer.zero_grad()): forget the previous step's counts."""
-        self._count, self._work, self.early_launched_in_backward = 0, [], False
+        self._count, self._work, self.early_launched_in_backward, self._reduced = 0, [], False, False
 
     def _active(self):
         return self.enabled and dist.is_initialized() and dist.get_world_size() > 1
 
+    def _early_grads_in_flat(self):
+        """True when every early parameter's .grad still IS its slice of the flat buffer.  After `module.zero_grad()` (torch's
+        set_to_none=True) or `p.grad = None` autograd installs fresh tensors: the slice then holds nothing of this step and must
+        not go on the wire from the hook - finish() reduces it after the optimiser has folded the gradients back in."""
+        lo = self.flat.data_ptr()
+        hi = lo + self.flat.numel() * self.flat.element_size()
+        for p in self._early:
+            g = p.grad
+            if g is None or not (lo <= g.data_ptr() < hi):
+                return False
+        return True
+
     def _arrived(self, _param):
         self._count += 1
-        if self._count == self._early_n and self._active():
+        if not self._active():
+            return
+        if self._count > self._early_n and (self.early_launched_in_backward or self._reduced):
+            raise RuntimeError("GradBuckets: a second backward pass reached the early parameters before the step ended "
+                               "(optimizer.zero_grad() / begin()): their slice is already being summed over the ranks")
+        if self._count == self._early_n and self._early_grads_in_flat():
             self._work.append(dist.all_reduce(self.flat[self.lo:self.hi], op=dist.ReduceOp.SUM, async_op=True))
             self.early_launched_in_backward = True
 
@@ -163,6 +201,8 @@ class GradBuckets:
         """After backward: reduce the rest, wait for everything, average.  Returns the bytes this rank put on the wire."""
         if not self._active():
             return 0
+        if self._reduced:
+            raise RuntimeError("GradBuckets.finish(): this step's gradients were already averaged")
         if self._early_n and not self.early_launched_in_backward:          # e.g. a parameter that took no part in this step
             self._work.append(dist.all_reduce(self.flat[self.lo:self.hi], op=dist.ReduceOp.SUM, async_op=True))
         for a, b in ((0, self.lo), (self.hi, self.n)):
@@ -172,7 +212,14 @@ class GradBuckets:
             w.wait()
         self._work = []
         self.flat[:self.n].div_(dist.get_world_size())
+        self._reduced = True
         return self.n * self.flat.element_size()
+
+    def wait_early(self):
+        """Block until the slice a backward hook put on the wire has arrived (before anything else writes into it)."""
+        for w in self._work:
+            w.wait()
+        self._work = []
 
 
 def finalize():

@@ -75,14 +75,30 @@ class FusedAdam(torch.optim.Optimizer):
 
     def allreduce(self):
         """Average the flat gradient buffers over the process group (identity without one): waits for the slice a backward hook has
-        already put on the wire (`overlap_early`) and reduces the rest.  Call between backward() and step().  Returns bytes reduced."""
+        already put on the wire (`overlap_early`) and reduces the rest.  Call between backward() and step() - step() does it itself
+        if the caller did not (the stock train.py loop with only the constructor swapped).  Returns bytes reduced."""
         total = 0
         for f in self._flat:
             if f is None:
                 continue
+            b = f["buckets"]
+            if b.early_launched_in_backward:
+                b.wait_early()                # nothing may be folded into a slice that is still on the wire
             self._rebind(f)
-            total += f["buckets"].finish()
+            total += b.finish()
         return total
+
+    def close(self):
+        """Detach from the parameters' backward hooks (call before building another optimiser over the same parameters)."""
+        for f in self._flat:
+            if f is not None:
+                f["buckets"].close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                     # noqa: BLE001 - interpreter shutdown
+            pass
 
     # -- torch.optim.Adam's checkpoint surface: per-parameter `step`, `exp_avg`, `exp_avg_sq` (the moments live in flat buffers here)
     def state_dict(self):
@@ -129,6 +145,12 @@ class FusedAdam(torch.optim.Optimizer):
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
                 continue
+            b = f["buckets"]
+            if b._active() and not b._reduced:      # the caller did not run the exchange: do it here rather than step on local gradients
+                if b.early_launched_in_backward:
+                    b.wait_early()
+                self._rebind(f)
+                b.finish()
             self._rebind(f)
             f["step"] += 1
             b1, b2 = group["betas"]

@@ -135,6 +135,40 @@ TRAIN_WORKER = textwrap.dedent("""
         assert torch.allclose(flat_g, sum(both) / ws, rtol=1e-6, atol=1e-8)
         opt.step()
     assert seen == [True] * 3, seen                        # the early slice was on the wire before fusion's backward finished
+    # a step after `module.zero_grad()` (set_to_none=True, torch's default): autograd installs FRESH .grad tensors, the flat slice
+    # holds nothing of this step - the hook must not put it on the wire; the optimiser folds the gradients back in (FusedAdam._rebind)
+    # and finish() reduces everything afterwards
+    flat_g.zero_(); buckets.begin()
+    regis.zero_grad()
+    assert all(p.grad is None for p in regis.parameters())
+    x = torch.randn(8, 64, generator=torch.Generator().manual_seed(100 * rank + 9))
+    (regis(fusion(x)) ** 2).mean().backward()
+    assert not buckets.early_launched_in_backward
+    off = 0
+    for p in params:
+        k = p.numel()
+        view = flat_g[off:off + k].view(p.shape)
+        if p.grad.data_ptr() != view.data_ptr():
+            view.add_(p.grad); p.grad = view
+        off += k
+    local = flat_g.clone()
+    assert float(local[buckets.lo:buckets.hi].abs().sum()) > 0
+    buckets.finish()
+    both = [torch.zeros_like(local) for _ in range(ws)]
+    torch.distributed.all_gather(both, local)
+    assert torch.allclose(flat_g, sum(both) / ws, rtol=1e-6, atol=1e-8)
+    try:
+        buckets.finish()
+        raise SystemExit("a second finish() in one step must be refused")
+    except RuntimeError:
+        pass
+    # a rebuilt bucket takes over: the old one's hooks are gone once it is closed
+    buckets.close()
+    b2 = hdist.GradBuckets(flat_g, params, early=list(regis.parameters()))
+    flat_g.zero_(); b2.begin()
+    (regis(fusion(x)) ** 2).mean().backward()
+    assert b2.early_launched_in_backward and not buckets.early_launched_in_backward
+    b2.finish()
     mine = flat_p.clone()
     both = [torch.zeros_like(mine) for _ in range(ws)]
     torch.distributed.all_gather(both, mine)
@@ -161,3 +195,23 @@ def test_two_rank_train_loop_with_overlapped_exchange(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     assert "train loop ok" in outs[0][0]
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` launched directly (no torchrun environment) starts two ranks itself, before any GPU call, and rank
+    0's line says n_gpus 2 with both ranks seen by an all_gather.  Here: no ROCm device, HRN_DIST_BACKEND=gloo = the launcher
+    rehearsal on CPU stand-in steps (no kernel runs, value is null).  Without that variable, or with fewer devices than ranks, the
+    command refuses instead of silently measuring one GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for mode in ("forward", "train"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode],
+                           env=dict(env, HRN_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["backend"] == "gloo"
+        assert line["value"] is None and line["rehearsal"] is True and line["mode"] == mode
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

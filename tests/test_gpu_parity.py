@@ -78,15 +78,58 @@ def test_hrnet_config1_shape(prec):
     _check(prec, sr, g["sr"])
 
 
-@pytest.mark.parametrize("shape", [(1, 2, 20), (3, 3, 8), (1, 7, 40), (2, 9, 33), (1, 16, 12)])
-def test_hrnet_edge_shapes_vs_oracle(shape):
-    """Sizes that do not fill the 8x32 tile, odd view counts, tiny images; fp32 path vs the fp64 numpy oracle."""
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 2, 20), (3, 3, 8), (1, 7, 40), (2, 9, 33), (1, 16, 12), (1, 4, 72)])
+def test_hrnet_edge_shapes_vs_oracle(shape, prec):
+    """Sizes that do not fill the 8x32 / 16x32 tiles, odd view counts, tiny images, and one image (72) that spans more than two
+    tiles in both directions without being a tile multiple: the fp32 AND the bf16 path vs the fp64 numpy oracle."""
     b, v, s = shape
     lrs, alphas, _ = synth.make_batch(1000 + s, b, v, s, [max(1, v - i) for i in range(b)])
     want = O.hrnet_forward(lrs, alphas, weights.hrnet_state(1234))
     with torch.no_grad():
-        sr = util.hip_hrnet("fp32")(util.dev(lrs), util.dev(alphas)).cpu().numpy()
-    assert util.rel_err(sr, want) <= FP32_GUARD
+        sr = util.hip_hrnet(prec)(util.dev(lrs), util.dev(alphas)).cpu().numpy()
+    if prec == "fp32":
+        assert util.rel_err(sr, want) <= FP32_GUARD
+    else:
+        _check(prec, sr, want)
+
+
+def test_general_conv_kernel_route_vs_reference_golden():
+    """The bf16 layers that conv3x3_r64 / conv3x3_v6 decline (images beyond their 32-bit in-image offsets) run on the general kernel
+    of conv3x3.hip.  No BASELINE config is that large, so the route is forced (HRN_CONV_R64=0 HRN_CONV_V6=0, read once per process:
+    a fresh interpreter started before any GPU call) and checked against the reference's own outputs, ragged sizes included."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, numpy as np, torch\n"
+        f"sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.dirname(os.path.abspath(__file__))!r}]\n"
+        "import conftest, util\n"
+        "from oracle import hrnet_np as O, synth, weights\n"
+        "worst = 0.0\n"
+        "for name in ('hrnet_b2_v5_s16', 'hrnet_b1_v12_s24', 'hrnet_b1_v32_s32'):\n"
+        "    g = util.golden(name)\n"
+        "    with torch.no_grad():\n"
+        "        sr = util.hip_hrnet('bf16')(util.dev(g['lrs']), util.dev(g['alphas'])).cpu().numpy()\n"
+        "    e, ps = util.rel_err(sr, g['sr']), util.psnr_db(sr, g['sr'])\n"
+        "    assert e <= 2.5e-2 and ps >= 45.0, (name, e, ps)\n"
+        "lrs, alphas, _ = synth.make_batch(1072, 1, 4, 72, [4])\n"
+        "want = O.hrnet_forward(lrs, alphas, weights.hrnet_state(1234))\n"
+        "with torch.no_grad():\n"
+        "    sr = util.hip_hrnet('bf16')(util.dev(lrs), util.dev(alphas)).cpu().numpy()\n"
+        "e, ps = util.rel_err(sr, want), util.psnr_db(sr, want)\n"
+        "assert e <= 2.5e-2 and ps >= 45.0, ('72', e, ps)\n"
+        "from hrnet_hip import binding\n"
+        "binding.profile_enable(True)\n"
+        "with torch.no_grad():\n"
+        "    util.hip_hrnet('bf16')(util.dev(lrs), util.dev(alphas))\n"
+        "torch.cuda.synchronize(); binding.profile_enable(False)\n"
+        "print('FAMILIES', sorted(binding.profile_read()))\n"
+    )
+    env = dict(os.environ, HRN_CONV_R64="0", HRN_CONV_V6="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    # the general kernel files every layer under the plain family names; r64 / v6 would have filed their residual layers under "...+res"
+    assert "conv3x3_bf16_128x128" in r.stdout and "conv3x3_bf16_64x64" in r.stdout and "+res" not in r.stdout
 
 
 def test_hrnet_other_weights_and_layers():
