@@ -580,7 +580,8 @@ def measure_rank0(args, ws, device, net, lrs, alphas, step, sr_holder, binding, 
             binding._ws_cache.clear()
             torch.cuda.empty_cache()
             tstep = make_train_step(device, 32, 32, 64)
-            t = timed_local(tstep, 3, 2, device) / 3
+            with torch.enable_grad():
+                t = timed_local(tstep, 3, 2, device) / 3
             return {"ms_per_step": round(t * 1e3, 1), "samples_per_s": round(32 / t, 1), "steps": 3,
                     "workload": "src/train.py:164-191 on the HIP modules, B=32, n_views=32, 64x64 patches, fp32 (python bench.py --mode train)"}
         extra(extras, "train_step", train)
