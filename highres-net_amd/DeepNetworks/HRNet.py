@@ -10,6 +10,8 @@ the same order).  None of the sub-modules is ever called: `HRNet.forward` hands 
 Precision (`HRNet.precision`, or key "precision" in the config dict, or env HRNET_HIP_PRECISION):
     "fp32" (default)  exact-fp32 MFMA; matches the reference forward to ~1e-6 relative
     "bf16"            bf16 activations/weights, fp32 accumulation; the throughput path (BASELINE config 3)
+    "bf16x3"          split-bf16: every fp32 value as a (hi, lo) pair of bf16, three bf16 MFMAs per product, fp32 accumulation;
+                      matches the reference forward to ~1e-5 relative at ~3x the fp32 path's speed
 """
 import os
 
@@ -18,7 +20,8 @@ import torch.nn as nn
 
 from hrnet_hip import binding
 
-_PRECISIONS = {"fp32": binding.F32, "f32": binding.F32, "float32": binding.F32, "bf16": binding.BF16, "bfloat16": binding.BF16}
+_PRECISIONS = {"fp32": binding.F32, "f32": binding.F32, "float32": binding.F32, "bf16": binding.BF16, "bfloat16": binding.BF16,
+               "bf16x3": binding.BF16X3}
 
 
 class _Holder(nn.Module):

@@ -15,7 +15,20 @@ LIB_PATH = os.environ.get("HRNET_HIP_LIB") or os.path.join(_HERE, "libhrnet_hip.
 
 F32, BF16, BF16X3 = 0, 1, 2
 MAX_RES_LAYERS = 8
-_DT_TORCH = {F32: torch.float32, BF16: torch.bfloat16}
+_DT_TORCH = {F32: torch.float32, BF16: torch.bfloat16, BF16X3: torch.bfloat16}     # BF16X3: two bf16 planes (hi, lo), planes first
+
+
+def planes_to_float(t, dtype):
+    """A stage tensor as float32: bf16x3 stage tensors are (2, ...) bf16 pairs of planes, value = hi + lo."""
+    return t[0].float() + t[1].float() if dtype == BF16X3 else t.float()
+
+
+def float_to_planes(x, dtype):
+    """float32 -> the stage tensor of `dtype` (bf16x3: hi = bf16(x), lo = bf16(x - hi), stacked planes first)."""
+    if dtype == BF16X3:
+        hi = x.to(torch.bfloat16)
+        return torch.stack([hi, (x - hi.float()).to(torch.bfloat16)]).contiguous()
+    return x.to(_DT_TORCH[dtype]).contiguous()
 _fp = ctypes.POINTER(ctypes.c_float)
 
 
@@ -232,28 +245,28 @@ def hrnet_forward(packed, dtype, num_layers, alpha_residual, lrs, alphas, out=No
 
 
 def hrnet_encoder(packed, dtype, num_layers, lrs):
-    """-> view stack (B,V,H,W,64) channels-last in the storage dtype."""
+    """-> view stack (B,V,H,W,64) channels-last in the storage dtype ((2,B,V,H,W,64) bf16 planes for BF16X3)."""
     lib = load_library()
     lrs = _dev_f32(lrs, "lrs")
     B, V, H, W = lrs.shape
     with torch.cuda.device(lrs.device):
         ws = hrnet_workspace(dtype, B, V, H, W, lrs.device)
-        emb = torch.empty((B, V, H, W, 64), dtype=_DT_TORCH[dtype], device=lrs.device)
+        emb = torch.empty(((2,) if dtype == BF16X3 else ()) + (B, V, H, W, 64), dtype=_DT_TORCH[dtype], device=lrs.device)
         _check(lib.hrn_encoder_forward(_ptr(packed), dtype, num_layers, _ptr(lrs), B, V, H, W, _ptr(emb), _ptr(ws), ws.numel(),
                                        _stream()), "hrn_encoder_forward")
     return emb
 
 
 def hrnet_fuse(packed, dtype, num_layers, alpha_residual, emb, alphas):
-    """emb (B,V,H,W,64) storage dtype (destroyed) -> fused (B,H,W,64)."""
+    """emb (B,V,H,W,64) storage dtype (destroyed) -> fused (B,H,W,64); BF16X3: both with a leading plane axis of 2."""
     lib = load_library()
-    if emb.dtype != _DT_TORCH[dtype] or not emb.is_contiguous() or not emb.is_cuda:
+    if emb.dtype != _DT_TORCH[dtype] or not emb.is_contiguous() or not emb.is_cuda or emb.dim() != (6 if dtype == BF16X3 else 5):
         raise ValueError("emb must be a contiguous device tensor in the storage dtype")
-    B, V, H, W, _ = emb.shape
+    B, V, H, W, _ = emb.shape[-5:]
     alphas = _dev_f32(alphas, "alphas")
     with torch.cuda.device(emb.device):
         ws = hrnet_workspace(dtype, B, V, H, W, emb.device)
-        fused = torch.empty((B, H, W, 64), dtype=emb.dtype, device=emb.device)
+        fused = torch.empty(((2,) if dtype == BF16X3 else ()) + (B, H, W, 64), dtype=emb.dtype, device=emb.device)
         _check(lib.hrn_fuse_forward(_ptr(packed), dtype, num_layers, int(bool(alpha_residual)), _ptr(emb), _ptr(alphas),
                                     B, V, H, W, _ptr(fused), _ptr(ws), ws.numel(), _stream()), "hrn_fuse_forward")
     return fused
@@ -261,9 +274,9 @@ def hrnet_fuse(packed, dtype, num_layers, alpha_residual, emb, alphas):
 
 def hrnet_decoder(packed, dtype, num_layers, fused):
     lib = load_library()
-    if fused.dtype != _DT_TORCH[dtype] or not fused.is_contiguous() or not fused.is_cuda:
+    if fused.dtype != _DT_TORCH[dtype] or not fused.is_contiguous() or not fused.is_cuda or fused.dim() != (5 if dtype == BF16X3 else 4):
         raise ValueError("fused must be a contiguous device tensor in the storage dtype")
-    N, H, W, _ = fused.shape
+    N, H, W, _ = fused.shape[-4:]
     with torch.cuda.device(fused.device):
         sr = torch.empty((N, 1, 3 * H, 3 * W), dtype=torch.float32, device=fused.device)
         _check(lib.hrn_decoder_forward(_ptr(packed), dtype, num_layers, _ptr(fused), N, H, W, _ptr(sr), _stream()), "hrn_decoder_forward")

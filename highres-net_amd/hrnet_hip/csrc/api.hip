@@ -41,8 +41,15 @@ HrnetWs hrnet_ws(int dt, int B, int V, int H, int W) {
     return w;
 }
 
+// HRN_BF16X3: every activation tensor of the workspace is a pair of bf16 planes; the lo plane of the view stack and of the two
+// ping-pong buffers starts half a stack further on (a plane of the fusion's 128-channel intermediates is at most that large), the lo
+// plane of the fused state B*HW*64 bf16 further on.  0 for the other dtypes.
+size_t stack_lo(int dt, int B, int V, int H, int W) { return dt == HRN_BF16X3 ? (size_t)B * V * H * W * 64 * 2 : 0; }
+size_t fused_lo(int dt, int B, int H, int W) { return dt == HRN_BF16X3 ? (size_t)B * H * W * 64 * 2 : 0; }
+bool dtype_ok(int dt) { return dt == HRN_F32 || dt == HRN_BF16 || dt == HRN_BF16X3; }
+
 int check_common(int dt, int nl, int B, int V, int H, int W) {
-    HRN_CHECK(dt == HRN_F32 || dt == HRN_BF16, -2, "dtype must be HRN_DTYPE_F32 or HRN_DTYPE_BF16 (got %d)", dt);
+    HRN_CHECK(dtype_ok(dt), -2, "dtype must be HRN_DTYPE_F32, HRN_DTYPE_BF16 or HRN_DTYPE_BF16X3 (got %d)", dt);
     HRN_CHECK(nl >= 0 && nl <= HRN_MAX_RES_LAYERS, -2, "num_layers %d out of range 0..%d", nl, HRN_MAX_RES_LAYERS);
     HRN_CHECK(B > 0 && V > 0 && H > 0 && W > 0, -2, "empty input B=%d V=%d H=%d W=%d", B, V, H, W);
     return 0;
@@ -58,22 +65,22 @@ int encoder_impl(const void* pk, int dt, int nl, const float* lrs, int B, int V,
     int rc;
     if ((rc = hrn_launch_median(lrs, ref, B, V, H, W, s))) return rc;
     // stem: channel 0 = view, channel 1 = the sample's reference frame; 2->64 + PReLU  (HRNet.py:200-204, :51-53)
-    void* stem_out = nl > 0 ? bufA : bufA;
+    const size_t lo = stack_lo(dt, B, V, H, W);        // bf16x3: lo plane of bufA / bufB / emb (0 otherwise)
     if ((rc = hrn_launch_stem(dt, lrs, hw, ref, V, hw, nullptr, (const float*)at(pk, L.stem_w), (const float*)at(pk, L.stem_b),
-                              (const float*)at(pk, L.stem_a), stem_out, B * V, H, W, s))) return rc;
+                              (const float*)at(pk, L.stem_a), bufA, B * V, H, W, s, lo))) return rc;
     // residual blocks: A -conv+PReLU-> B -conv+PReLU, + A-> A (in place: the residual is read at the stored pixel only)
     for (int l = 0; l < nl; ++l) {
         ConvParams p = conv_base(B * V, H, W);
-        p.in = bufA; p.out = bufB;
+        p.in = bufA; p.out = bufB; p.in_lo = p.out_lo = lo;
         p.wpk = at(pk, L.enc_w[2 * l]); p.bias = (const float*)at(pk, L.enc_b[2 * l]); p.slope = (const float*)at(pk, L.enc_a[2 * l]);
         if ((rc = hrn_launch_conv3x3(dt, 64, 64, p, s))) return rc;
         ConvParams q = conv_base(B * V, H, W);
-        q.in = bufB; q.out = bufA; q.res = bufA; q.res_mode = 1;
+        q.in = bufB; q.out = bufA; q.res = bufA; q.res_mode = 1; q.in_lo = q.out_lo = q.res_lo = lo;
         q.wpk = at(pk, L.enc_w[2 * l + 1]); q.bias = (const float*)at(pk, L.enc_b[2 * l + 1]); q.slope = (const float*)at(pk, L.enc_a[2 * l + 1]);
         if ((rc = hrn_launch_conv3x3(dt, 64, 64, q, s))) return rc;
     }
     ConvParams f = conv_base(B * V, H, W);
-    f.in = bufA; f.out = emb;
+    f.in = bufA; f.out = emb; f.in_lo = f.out_lo = lo;
     f.wpk = at(pk, L.encf_w); f.bias = (const float*)at(pk, L.encf_b); f.slope = nullptr;
     return hrn_launch_conv3x3(dt, 64, 64, f, s);
 }
@@ -84,6 +91,7 @@ int fuse_impl(const void* pk, int dt, int nl, int alpha_residual, void* emb, con
     const size_t hw = (size_t)H * W, es = hrn_esize(dt);
     void* t1 = at(ws, wl.buf_a);
     void* t2 = at(ws, wl.buf_b);
+    const size_t lo = stack_lo(dt, B, V, H, W), flo = fused_lo(dt, B, H, W);
     int n = V, rc;
     if (n / 2 == 0) {   // V == 1: no fusion level; mean over one view is the identity (HRNet.py:113,134)
         HRN_HIP(hipMemcpyAsync(fused, emb, (size_t)B * hw * 64 * es, hipMemcpyDeviceToDevice, s));
@@ -95,21 +103,21 @@ int fuse_impl(const void* pk, int dt, int nl, int alpha_residual, void* emb, con
         // g: z = cat(s_i, s_partner) -> t1 = PReLU(conv(z))                 (ResidualBlock first half, HRNet.py:18-19)
         ConvParams a = conv_base(B * half, H, W);
         a.in_pair = 1; a.stack = emb; a.pair_h = half; a.pair_last = n - parity - 1; a.pair_vs = V;
-        a.out = t1;
+        a.out = t1; a.stack_lo = a.out_lo = lo;
         a.wpk = at(pk, L.fres_w[0]); a.bias = (const float*)at(pk, L.fres_b[0]); a.slope = (const float*)at(pk, L.fres_a[0]);
         if ((rc = hrn_launch_conv3x3(dt, 128, 128, a, s))) return rc;
         // t2 = z + PReLU(conv(t1))                                          (HRNet.py:20-21, :33)
         ConvParams b = conv_base(B * half, H, W);
-        b.in = t1; b.out = t2;
+        b.in = t1; b.out = t2; b.in_lo = b.out_lo = b.stack_lo = lo;
         b.res_mode = 2;      // residual = the same pair gather, straight from the stack
         b.stack = emb; b.pair_h = half; b.pair_last = n - parity - 1; b.pair_vs = V;
         b.wpk = at(pk, L.fres_w[1]); b.bias = (const float*)at(pk, L.fres_b[1]); b.slope = (const float*)at(pk, L.fres_a[1]);
         if ((rc = hrn_launch_conv3x3(dt, 128, 128, b, s))) return rc;
         // f = PReLU(conv(t2)); s_i <- s_i + alpha_partner * f  (or s_i <- f)  (HRNet.py:95-97, :123-128)
         ConvParams c = conv_base(B * half, H, W);
-        c.in = t2;
+        c.in = t2; c.in_lo = c.res_lo = lo;
         c.out_h = half;
-        if (last) { c.out = fused; c.out_vs = 1; } else { c.out = emb; c.out_vs = V; }
+        if (last) { c.out = fused; c.out_vs = 1; c.out_lo = flo; } else { c.out = emb; c.out_vs = V; c.out_lo = lo; }
         c.pair_last = n - parity - 1;
         if (alpha_residual) { c.res_mode = 3; c.res = emb; c.res_vs = V; c.alphas = alphas; c.alpha_vs = V; }
         c.wpk = at(pk, L.fout_w); c.bias = (const float*)at(pk, L.fout_b); c.slope = (const float*)at(pk, L.fout_a);
@@ -122,7 +130,7 @@ int fuse_impl(const void* pk, int dt, int nl, int alpha_residual, void* emb, con
 int decoder_impl(const void* pk, int dt, int nl, const void* fused, int N, int H, int W, float* sr, hipStream_t s) {
     const HrnetLayout L = hrnet_layout(dt, nl);
     return hrn_launch_decoder(dt, fused, at(pk, L.dec_w), (const float*)at(pk, L.dec_b), (const float*)at(pk, L.dec_a),
-                              (const float*)at(pk, L.fin_w), (const float*)at(pk, L.fin_b), sr, N, H, W, s);
+                              (const float*)at(pk, L.fin_w), (const float*)at(pk, L.fin_b), sr, N, H, W, s, fused_lo(dt, N, H, W));
 }
 
 // ---------------------------------------------------------------- ShiftNet layouts (packed parameters: shiftnet_layout.h)
@@ -152,7 +160,7 @@ int hrn_version(void) { return HRN_ABI_VERSION; }
 const char* hrn_last_error(void) { return g_err; }
 
 size_t hrn_hrnet_packed_bytes(int dtype, int num_layers) {
-    if ((dtype != HRN_F32 && dtype != HRN_BF16) || num_layers < 0 || num_layers > HRN_MAX_RES_LAYERS) return 0;
+    if (!dtype_ok(dtype) || num_layers < 0 || num_layers > HRN_MAX_RES_LAYERS) return 0;
     return hrnet_layout(dtype, num_layers).total;
 }
 
@@ -185,14 +193,14 @@ int hrn_hrnet_pack(const hrn_hrnet_params* P, int dt, void* packed, size_t packe
     }
     if ((rc = hrn_launch_conv_pack(dt, 128, 64, P->fuse_out_w, at(packed, L.fout_w), s))) return rc;
     if ((rc = copy(L.fout_b, P->fuse_out_b, 64)) || (rc = copy(L.fout_a, P->fuse_out_a, 1))) return rc;
-    if ((rc = hrn_launch_decoder_pack(dt, P->dec_w, at(packed, L.dec_w), s))) return rc;
+    if ((rc = hrn_launch_decoder_pack(dt == HRN_BF16X3 ? HRN_F32 : dt, P->dec_w, at(packed, L.dec_w), s))) return rc;     // bf16x3: the decoder is the fp32 one
     if ((rc = copy(L.dec_b, P->dec_b, 64)) || (rc = copy(L.dec_a, P->dec_a, 1))) return rc;
     if ((rc = copy(L.fin_w, P->fin_w, 64)) || (rc = copy(L.fin_b, P->fin_b, 1))) return rc;
     return 0;
 }
 
 size_t hrn_hrnet_workspace_bytes(int dtype, int B, int V, int H, int W) {
-    if ((dtype != HRN_F32 && dtype != HRN_BF16) || B <= 0 || V <= 0 || H <= 0 || W <= 0) return 0;
+    if (!dtype_ok(dtype) || B <= 0 || V <= 0 || H <= 0 || W <= 0) return 0;
     return hrnet_ws(dtype, B, V, H, W).total;
 }
 
@@ -233,29 +241,8 @@ int hrn_hrnet_forward(const void* packed, int dt, int nl, int alpha_residual, co
     hipStream_t s = (hipStream_t)stream;
     void* emb = at(ws, wl.emb);
     void* fused = at(ws, wl.fused);
-    // Optional Infinity-Cache slicing: run encoder + fusion for a few samples at a time so that the layer-to-layer
-    // intermediates (two ping-pong buffers + the slice of the view stack, re-used by every slice) stay resident in the
-    // 256 MiB memory-side cache instead of making an HBM round trip per layer.  Results are bit-identical (samples are
-    // independent).  HRN_SLICE_MB = per-buffer budget in MiB; default 0 = whole batch in one go: measured at c3 the
-    // kernels are not HBM-bound yet and the smaller launches cost more in tails than residency gains (r01: 34.4 ms
-    // at 64 MiB slices vs 27.7 ms unsliced), so it stays a knob for later rounds.
-    static const long slice_mb = [] { const char* e = getenv("HRN_SLICE_MB"); return e ? atol(e) : 0L; }();     // read once (thread-safe init)
-    const size_t per_sample = (size_t)V * H * W * 64 * hrn_esize(dt);
-    int bs = B;
-    if (slice_mb > 0) {
-        const size_t budget = (size_t)slice_mb << 20;
-        bs = (int)(budget / per_sample);
-        if (bs < 1) bs = 1;
-        if (bs > B) bs = B;
-    }
-    const size_t hw = (size_t)H * W;
-    for (int b0 = 0; b0 < B; b0 += bs) {
-        const int nb = B - b0 < bs ? B - b0 : bs;
-        void* emb_s = at(emb, (size_t)b0 * per_sample);
-        void* fused_s = at(fused, (size_t)b0 * hw * 64 * hrn_esize(dt));
-        if ((rc = encoder_impl(packed, dt, nl, lrs + (size_t)b0 * V * hw, nb, V, H, W, emb_s, ws, wl, s))) return rc;
-        if ((rc = fuse_impl(packed, dt, nl, alpha_residual, emb_s, alphas + (size_t)b0 * V, nb, V, H, W, fused_s, ws, wl, s))) return rc;
-    }
+    if ((rc = encoder_impl(packed, dt, nl, lrs, B, V, H, W, emb, ws, wl, s))) return rc;
+    if ((rc = fuse_impl(packed, dt, nl, alpha_residual, emb, alphas, B, V, H, W, fused, ws, wl, s))) return rc;
     return decoder_impl(packed, dt, nl, fused, B, H, W, sr, s);
 }
 

@@ -7,6 +7,7 @@
 
 #define HRN_F32 0
 #define HRN_BF16 1
+#define HRN_BF16X3 2     // fp32 values as two bf16 planes (hi, lo); three bf16 MFMAs per product (conv3x3_v6x3.hip)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -113,4 +114,10 @@ template <> __device__ __forceinline__ void store4<HRN_BF16>(void* p, size_t i, 
 }
 
 static inline size_t hrn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// bytes per element of an activation / weight tensor (bf16x3: both planes together)
 static inline int hrn_esize(int dt) { return dt == HRN_BF16 ? 2 : 4; }
+// two floats -> their (hi, lo) bf16 split, packed like pack2_bf16: hi = bf16(v), lo = bf16(v - hi)
+__device__ __forceinline__ void split2_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pack2_bf16(a, b);
+    lo = pack2_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}

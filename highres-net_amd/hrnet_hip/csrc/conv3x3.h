@@ -24,6 +24,9 @@ struct ConvParams {
     int alpha_vs, res_vs;
     int relu;                         // 1: y = max(y, 0) after bias (ShiftNet eval with folded BN uses scale/shift below)
     const float* scale;               // optional per-channel scale applied before bias (folded BatchNorm), null = 1
+    // HRN_BF16X3 only: every activation tensor is a PAIR of bf16 planes (hi, lo) in the bf16 layout; byte offset of the lo plane from
+    // the hi plane of `in` / `stack` / `out` / `res` (0 otherwise)
+    size_t in_lo, stack_lo, out_lo, res_lo;
     const float* only_if_nonpos;      // f32 kernel only: when set, the launch does nothing unless only_if_nonpos[0] <= 0 (the backward's
                                       // recomputation of a pre-activation, needed only behind a PReLU whose slope is not positive)
 };
@@ -40,6 +43,10 @@ int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream);
 // bf16 128 -> {128, 64}: the three layers of a fusion level; descriptor-based halo DMA issued from the MFMA gaps, epilogue straight
 // from the accumulators in whole pixel rows (conv3x3_v6.hip); -100 = not applicable.
 int hrn_launch_conv3x3_v6(int cout, const ConvParams& p, hipStream_t stream);
+
+// bf16x3 (split-bf16: hi/lo planes, three MFMAs per product) on the conv3x3_v6 skeleton: (cin, cout) = (64, 64) with res_mode 0 | 1,
+// (128, 128) with 0 | 2 (+ pair-gather input), (128, 64) with 0 | 3 (conv3x3_v6x3.hip).  No other kernel implements this dtype.
+int hrn_launch_conv3x3_v6x3(int cin, int cout, const ConvParams& p, hipStream_t stream);
 
 // Pack OIHW f32 weights [cout][cin][3][3] into the kernel's step-major layout (device to device).
 int hrn_launch_conv_pack(int dt, int cin, int cout, const float* w_oihw, void* packed, hipStream_t stream);

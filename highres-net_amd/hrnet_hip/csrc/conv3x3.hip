@@ -354,6 +354,26 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, void* __restrict__
     }
 }
 
+// bf16x3: the bf16 layout twice - plane 0 holds hi = bf16(w), plane 1 (total elements further on) lo = bf16(w - hi)
+__global__ void conv_pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cin, int cout) {
+    constexpr int KB = 64;
+    const int nhalf = cout / 64;
+    const size_t total = (size_t)cin * cout * 9;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(idx % KB);
+        const int col = (int)((idx / KB) % 64);
+        const int step = (int)(idx / ((size_t)KB * 64));
+        const int half = step % nhalf;
+        const int ct = step / nhalf;
+        const int tap = ct % 9, chunk = ct / 9;
+        const int co = half * 64 + col, ci = chunk * KB + kk;
+        const float v = w[((size_t)co * cin + ci) * 9 + tap];
+        const unsigned short h = f32_to_bf16_bits(v);
+        out[idx] = h;
+        out[total + idx] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+    }
+}
+
 }  // namespace
 
 int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream_t stream) {
@@ -362,6 +382,7 @@ int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream
     HRN_CHECK(p.res_mode != 2 || (p.pair_h > 0 && p.stack && cout == 128), -2, "conv3x3: res_mode 2 needs a pair descriptor and cout=128");
     HRN_CHECK(p.in_pair || p.in, -2, "conv3x3: null input");
     HRN_CHECK(p.res_mode != 3 || p.out_h > 0, -2, "conv3x3: res_mode 3 needs slot output");
+    if (dt == HRN_BF16X3) return hrn_launch_conv3x3_v6x3(cin, cout, p, stream);      // the only kernel of this precision mode
     if (dt == HRN_BF16 && !p.scale && !p.relu) {
         // the HRNet layers in bf16: resident-weights kernel (conv3x3_r64.hip) for the encoder's 64 -> 64 layers, conv3x3_v6.hip for the
         // three layers of a fusion level.  What they decline (images beyond their 32-bit in-image offsets, > 8.3 Mpixel) runs on this
@@ -389,7 +410,8 @@ int hrn_launch_conv_pack(int dt, int cin, int cout, const float* w, void* packed
     HRN_CHECK((cin == 64 || cin == 128) && (cout == 64 || cout == 128), -2, "conv pack: unsupported channels %d->%d", cin, cout);
     const size_t total = (size_t)cin * cout * 9;
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    if (dt == HRN_BF16) hipLaunchKernelGGL(conv_pack_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, w, packed, cin, cout);
+    if (dt == HRN_BF16X3) hipLaunchKernelGGL(conv_pack_x3_kernel, dim3(blocks), dim3(256), 0, stream, w, (unsigned short*)packed, cin, cout);
+    else if (dt == HRN_BF16) hipLaunchKernelGGL(conv_pack_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, w, packed, cin, cout);
     else hipLaunchKernelGGL(conv_pack_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, w, packed, cin, cout);
     HRN_LAUNCH_CHECK();
     return 0;

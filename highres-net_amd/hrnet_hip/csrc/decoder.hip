@@ -17,11 +17,13 @@ namespace {
 constexpr int W_ROW_PITCH = 144;
 constexpr int W_BUF_BYTES = 64 * W_ROW_PITCH;
 
-template <int DT>
+// SPLIT (DT = HRN_F32 only): the input is the bf16x3 pair of planes (hi at `fused`, lo `fused_lo` bytes further on); the pixel operand is
+// formed as float(hi) + float(lo) on the way into the registers and everything after it is the fp32 decoder.
+template <int DT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void decoder_kernel(const void* __restrict__ fused, const void* __restrict__ wpk,
                                                          const float* __restrict__ bias, const float* __restrict__ slope,
                                                          const float* __restrict__ wf, const float* __restrict__ bfin,
-                                                         float* __restrict__ sr, size_t npix, int H, int W) {
+                                                         float* __restrict__ sr, size_t npix, int H, int W, size_t fused_lo) {
     __shared__ __attribute__((aligned(16))) unsigned char w_lds[2 * W_BUF_BYTES];
     __shared__ __attribute__((aligned(16))) float bias_l[64];
     __shared__ __attribute__((aligned(16))) float wf_l[64];
@@ -49,11 +51,28 @@ __global__ __launch_bounds__(256, 2) void decoder_kernel(const void* __restrict_
     for (int pb = 0; pb < 2; ++pb) {
         pixel[pb] = (size_t)blockIdx.x * 256 + wave * 64 + pb * 32 + r;
         const size_t pc = pixel[pb] < npix ? pixel[pb] : npix - 1;
+        if constexpr (SPLIT) {
+            // f32 fragment piece (c, k) = channels 32 c + 8 k + 4 hh .. + 3: 8 bytes of each bf16 plane
+            const unsigned char* src = (const unsigned char*)fused + pc * 128 + hh * 8;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint2 h = *(const uint2*)(src + c * 64 + k * 16), l = *(const uint2*)(src + fused_lo + c * 64 + k * 16);
+                    uint4 v;
+                    v.x = __float_as_uint(__uint_as_float(h.x << 16) + __uint_as_float(l.x << 16));
+                    v.y = __float_as_uint(__uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u));
+                    v.z = __float_as_uint(__uint_as_float(h.y << 16) + __uint_as_float(l.y << 16));
+                    v.w = __float_as_uint(__uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u));
+                    breg[pb][c][k] = v;
+                }
+        } else {
         const unsigned char* src = (const unsigned char*)fused + pc * 64 * ES + hh * 16;
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
             for (int k = 0; k < 4; ++k) breg[pb][c][k] = *(const uint4*)(src + c * 128 + k * 32);
+        }
     }
     __syncthreads();
 
@@ -171,16 +190,19 @@ __global__ void decoder_pack_kernel(const float* __restrict__ w, void* __restric
 }  // namespace
 
 int hrn_launch_decoder(int dt, const void* fused, const void* wpk, const float* bias, const float* slope,
-                       const float* wf, const float* bf, float* sr, int N, int H, int W, hipStream_t stream) {
+                       const float* wf, const float* bf, float* sr, int N, int H, int W, hipStream_t stream, size_t fused_lo) {
     const size_t npix = (size_t)N * H * W;
     HRN_CHECK(npix > 0, -2, "decoder: empty input");
     const unsigned blocks = (unsigned)((npix + 255) / 256);
-    HrnProfScope prof(dt == HRN_BF16 ? "decoder_bf16" : "decoder_f32", (2.0 * 64 * 576 + 2.0 * 576) * npix,
+    HrnProfScope prof(dt == HRN_BF16 ? "decoder_bf16" : dt == HRN_BF16X3 ? "decoder_bf16x3" : "decoder_f32", (2.0 * 64 * 576 + 2.0 * 576) * npix,
                       (double)npix * (64.0 * hrn_esize(dt) + 36.0), stream);
     if (dt == HRN_BF16)
-        hipLaunchKernelGGL(decoder_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, fused, wpk, bias, slope, wf, bf, sr, npix, H, W);
-    else
-        hipLaunchKernelGGL(decoder_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, fused, wpk, bias, slope, wf, bf, sr, npix, H, W);
+        hipLaunchKernelGGL((decoder_kernel<HRN_BF16, false>), dim3(blocks), dim3(256), 0, stream, fused, wpk, bias, slope, wf, bf, sr, npix, H, W, (size_t)0);
+    else if (dt == HRN_BF16X3) {
+        HRN_CHECK(fused_lo != 0, -2, "decoder bf16x3: lo-plane offset missing");
+        hipLaunchKernelGGL((decoder_kernel<HRN_F32, true>), dim3(blocks), dim3(256), 0, stream, fused, wpk, bias, slope, wf, bf, sr, npix, H, W, fused_lo);
+    } else
+        hipLaunchKernelGGL((decoder_kernel<HRN_F32, false>), dim3(blocks), dim3(256), 0, stream, fused, wpk, bias, slope, wf, bf, sr, npix, H, W, (size_t)0);
     HRN_LAUNCH_CHECK();
     return 0;
 }

@@ -8,7 +8,8 @@
 int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, hipStream_t stream);
 int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1,
                     const float* sub, const float* w, const float* bias, const float* slope, void* out,
-                    int M, int H, int W, hipStream_t stream);
+                    int M, int H, int W, hipStream_t stream, size_t out_lo = 0);       // out_lo: HRN_BF16X3's lo-plane byte offset
+int hrn_launch_planes_to_f32(const void* hi, size_t lo_off, float* out, size_t n, hipStream_t stream);
 int hrn_launch_stem_pre(const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1, const float* w,
                         const float* bias, float* out, int M, int H, int W, const float* only_if_nonpos, hipStream_t stream);
 int hrn_launch_plane_mean(const float* x, float* mean, int planes, size_t hw, hipStream_t stream);
@@ -16,7 +17,7 @@ int hrn_launch_plane_mean(const float* x, float* mean, int planes, size_t hw, hi
 // ---- decoder.hip
 // fused [N][HW][64] (dt) -> sr [N][3H][3W] f32.  wpk: packed deconv weights (hrn_launch_decoder_pack), bias/slope/wf/bf f32.
 int hrn_launch_decoder(int dt, const void* fused, const void* wpk, const float* bias, const float* slope,
-                       const float* wf, const float* bf, float* sr, int N, int H, int W, hipStream_t stream);
+                       const float* wf, const float* bf, float* sr, int N, int H, int W, hipStream_t stream, size_t fused_lo = 0);
 int hrn_launch_decoder_pack(int dt, const float* w_iokk, void* packed, hipStream_t stream);
 
 // ---- lanczos.hip

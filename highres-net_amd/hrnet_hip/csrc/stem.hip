@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0
                                                    const float* __restrict__ sub,   // [M][2] per-plane means or null
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ slope, void* __restrict__ out,
-                                                   int M, int H, int W, const float* __restrict__ only_if_nonpos) {
+                                                   int M, int H, int W, const float* __restrict__ only_if_nonpos, size_t out_lo) {
     if (only_if_nonpos && only_if_nonpos[0] > 0.f) return;      // (ConvParams::only_if_nonpos)
     __shared__ __attribute__((aligned(16))) float wl[18 * 64];
     __shared__ __attribute__((aligned(16))) float bl[64];
@@ -123,7 +123,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0
                     v0[j] = t0 >= 0.f ? t0 : a * t0;
                     v1[j] = t1 >= 0.f ? t1 : a * t1;
                 }
-                if constexpr (DT == HRN_BF16) {
+                if constexpr (DT == HRN_BF16X3) {         // the fp32 result as (hi, lo) bf16 planes, lo plane out_lo bytes further on
+                    unsigned h[4], l[4];
+                    split2_bf16(v0[0], v0[1], h[0], l[0]); split2_bf16(v0[2], v0[3], h[1], l[1]);
+                    split2_bf16(v1[0], v1[1], h[2], l[2]); split2_bf16(v1[2], v1[3], h[3], l[3]);
+                    const u32x4 uh = {h[0], h[1], h[2], h[3]}, ul = {l[0], l[1], l[2], l[3]};
+                    *(u32x4*)((unsigned short*)out + o) = uh;
+                    *(u32x4*)((unsigned char*)out + out_lo + o * 2) = ul;
+                } else if constexpr (DT == HRN_BF16) {
                     u32x4 u;
                     u[0] = pack2_bf16(v0[0], v0[1]); u[1] = pack2_bf16(v0[2], v0[3]);
                     u[2] = pack2_bf16(v1[0], v1[1]); u[3] = pack2_bf16(v1[2], v1[3]);
@@ -266,6 +273,23 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
     if (threadIdx.x == 0) mean[blockIdx.x] = (float)(red[0] / (double)hw);
 }
 
+// 8 elements per thread: out = float(hi) + float(lo)
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const u32x4* __restrict__ hi, const u32x4* __restrict__ lo, float* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const u32x4 h = hi[i], l = lo[i];
+        f32x4 a, b;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            a[2 * k] = __uint_as_float(h[k] << 16) + __uint_as_float(l[k] << 16);
+            a[2 * k + 1] = __uint_as_float(h[k] & 0xffff0000u) + __uint_as_float(l[k] & 0xffff0000u);
+            b[2 * k] = __uint_as_float(h[2 + k] << 16) + __uint_as_float(l[2 + k] << 16);
+            b[2 * k + 1] = __uint_as_float(h[2 + k] & 0xffff0000u) + __uint_as_float(l[2 + k] & 0xffff0000u);
+        }
+        *(f32x4*)(out + i * 8) = a;
+        *(f32x4*)(out + i * 8 + 4) = b;
+    }
+}
+
 }  // namespace
 
 int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, hipStream_t stream) {
@@ -279,22 +303,26 @@ int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, 
 
 int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1,
                     const float* sub, const float* w, const float* bias, const float* slope, void* out,
-                    int M, int H, int W, hipStream_t stream) {
+                    int M, int H, int W, hipStream_t stream, size_t out_lo) {
     const size_t patches = (size_t)M * ((H + 3) / 4) * ((W + 31) / 32);
     const int blocks = (int)(patches < 16384 ? patches : 16384);
     const double px = (double)M * H * W;
-    HrnProfScope prof(dt == HRN_BF16 ? "stem2x64_bf16" : "stem2x64_f32", 2.0 * 18 * 64 * px, px * (4 + (double)M / rep1 / M * 4 + 64.0 * hrn_esize(dt)), stream);
+    HrnProfScope prof(dt == HRN_BF16 ? "stem2x64_bf16" : dt == HRN_BF16X3 ? "stem2x64_bf16x3" : "stem2x64_f32", 2.0 * 18 * 64 * px, px * (4 + (double)M / rep1 / M * 4 + 64.0 * hrn_esize(dt)), stream);
     if (dt == HRN_BF16 && sub == nullptr) {
         const size_t nseg = (size_t)M * H * ((W + 31) / 32);
         const int mblocks = (int)((nseg + 3) / 4 < 8192 ? (nseg + 3) / 4 : 8192);
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(mblocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, w, bias, slope,
                            (unsigned short*)out, M, H, W);
+    } else if (dt == HRN_BF16X3) {
+        HRN_CHECK(out_lo != 0, -2, "stem bf16x3: lo-plane offset missing");
+        hipLaunchKernelGGL(stem_kernel<HRN_BF16X3>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W,
+                           (const float*)nullptr, out_lo);
     } else if (dt == HRN_BF16)
         hipLaunchKernelGGL(stem_kernel<HRN_BF16>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W,
-                           (const float*)nullptr);
+                           (const float*)nullptr, (size_t)0);
     else
         hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W,
-                           (const float*)nullptr);
+                           (const float*)nullptr, (size_t)0);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -305,7 +333,18 @@ int hrn_launch_stem_pre(const float* in0, size_t img_stride0, const float* in1, 
     const size_t patches = (size_t)M * ((H + 3) / 4) * ((W + 31) / 32);
     const int blocks = (int)(patches < 16384 ? patches : 16384);
     hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, (const float*)nullptr, w, bias,
-                       (const float*)nullptr, (void*)out, M, H, W, only_if_nonpos);
+                       (const float*)nullptr, (void*)out, M, H, W, only_if_nonpos, (size_t)0);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16x3: (hi, lo) bf16 planes -> f32 (the fused state before the fp32 decoder; staged tensors for the tests)
+int hrn_launch_planes_to_f32(const void* hi, size_t lo_off, float* out, size_t n, hipStream_t stream) {
+    HRN_CHECK(n % 8 == 0 && lo_off % 16 == 0, -2, "planes_to_f32: %zu elements / lo offset %zu not aligned", n, lo_off);
+    const size_t n8 = n / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    HrnProfScope prof("planes_to_f32", 0.0, (double)n * 8, stream);
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3(blocks), dim3(256), 0, stream, (const u32x4*)hi, (const u32x4*)((const unsigned char*)hi + lo_off), out, n8);
     HRN_LAUNCH_CHECK();
     return 0;
 }

@@ -32,6 +32,10 @@
  *   - dtype selects storage of activations and the MFMA input type:
  *       HRN_DTYPE_F32  : f32 activations, v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation)
  *       HRN_DTYPE_BF16 : bf16 activations/weights, v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ *       HRN_DTYPE_BF16X3 : every fp32 activation / weight as two bf16 planes (hi = bf16(v), lo = bf16(v - hi)); a product is
+ *                        hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-16 per product): the
+ *                        reference's fp32 arithmetic (train.py:168-171, predict.py:36-37) to ~1e-5 at a third of the bf16
+ *                        matrix rate.  Stage tensors (emb, fused) are [2 planes][...][64] bf16, lo plane directly behind hi.
  *     inputs (lrs, alphas, ShiftNet pairs, Lanczos images) and the SR output are always f32.
  */
 #ifndef HRNET_HIP_H
@@ -44,6 +48,7 @@ extern "C" {
 
 #define HRN_DTYPE_F32 0
 #define HRN_DTYPE_BF16 1
+#define HRN_DTYPE_BF16X3 2
 #define HRN_MAX_RES_LAYERS 8
 #define HRN_ABI_VERSION 1
 
@@ -85,7 +90,8 @@ int hrn_hrnet_forward(const void* packed, int dtype, int num_layers, int alpha_r
                       const float* lrs, const float* alphas, int B, int V, int H, int W,
                       float* sr, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Stages (same workspace).  emb: view stack [B][V][H][W][64] in `dtype` (channels-last); fused: [B][H][W][64]. */
+/* Stages (same workspace).  emb: view stack [B][V][H][W][64] in `dtype` (channels-last); fused: [B][H][W][64].
+ * HRN_DTYPE_BF16X3: emb is [2][B][V][H][W][64] bf16 and fused [2][B][H][W][64] bf16 (plane 0 = hi, plane 1 = lo). */
 int hrn_encoder_forward(const void* packed, int dtype, int num_layers, const float* lrs, int B, int V, int H, int W,
                         void* emb, void* workspace, size_t workspace_bytes, void* stream);
 /* Destroys `emb` (levels are reduced in place, HRNet.py:113-132). */

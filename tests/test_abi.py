@@ -36,10 +36,10 @@ def test_version_and_sizes(lib):
     assert lib.hrn_version() == 1
     # packed HRNet parameters: every conv weight once, in the storage dtype (+ small f32 tensors, 256-B aligned)
     w_elems = 4 * 64 * 64 * 9 + 64 * 64 * 9 + 2 * 128 * 128 * 9 + 128 * 64 * 9 + 64 * 64 * 9
-    for dt, es in ((0, 4), (1, 2)):
+    for dt, es in ((0, 4), (1, 2), (2, 4)):       # f32, bf16, bf16x3 (two bf16 planes; fp32 decoder weights)
         n = lib.hrn_hrnet_packed_bytes(dt, 2)
         assert w_elems * es < n < w_elems * es + 64 * 1024
-    assert lib.hrn_hrnet_packed_bytes(2, 2) == 0 and lib.hrn_hrnet_packed_bytes(0, 99) == 0
+    assert lib.hrn_hrnet_packed_bytes(3, 2) == 0 and lib.hrn_hrnet_packed_bytes(0, 99) == 0
     # workspace: reference frame + 3 view stacks + fused state
     B, V, H = 32, 32, 128
     stack = B * V * H * H * 64 * 2

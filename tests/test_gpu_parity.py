@@ -24,6 +24,7 @@ pytestmark = pytest.mark.gpu
 
 FP32_CONTRACT, FP32_GUARD = 1e-3, 2e-5
 BF16_REL, BF16_PSNR = 2.5e-2, 45.0
+X3_REL = 1e-4          # bf16x3 (split-bf16, three MFMAs per product): inside the 1e-3 contract by 10x; measured worst ~2e-5
 
 HR_CASES = ["hrnet_b1_v1_s16", "hrnet_b2_v5_s16", "hrnet_b2_v6_s16_pad", "hrnet_b1_v12_s24", "hrnet_b2_v4_s16_noalpha",
             "hrnet_b1_v32_s32"]
@@ -33,6 +34,12 @@ def _check(prec, got, want):
     if prec == "fp32":
         e = util.rel_err(got, want)
         assert e <= FP32_CONTRACT and e <= FP32_GUARD, e
+    elif prec == "bf16x3":
+        e = util.rel_err(got, want)
+        if os.environ.get("HRN_TEST_RECORD"):
+            with open(os.environ["HRN_TEST_RECORD"], "a") as f:
+                f.write(f"bf16x3 {e:.4e}\n")
+        assert e <= FP32_CONTRACT and e <= X3_REL, e
     else:
         if os.environ.get("HRN_TEST_RECORD"):      # measured margins of the bf16 bounds: one line per check
             with open(os.environ["HRN_TEST_RECORD"], "a") as f:
@@ -40,7 +47,7 @@ def _check(prec, got, want):
         assert util.rel_err(got, want) <= BF16_REL and util.psnr_db(got, want) >= BF16_PSNR, (util.rel_err(got, want), util.psnr_db(got, want))
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("name", HR_CASES)
 def test_hrnet_forward_vs_reference_golden(name, prec):
     g = util.golden(name)
@@ -51,7 +58,7 @@ def test_hrnet_forward_vs_reference_golden(name, prec):
     _check(prec, sr.cpu().numpy(), g["sr"])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("name", ["hrnet_b2_v5_s16", "hrnet_b2_v6_s16_pad", "hrnet_b1_v1_s16"])
 def test_hrnet_stages_vs_reference_golden(name, prec):
     g = util.golden(name)
@@ -59,15 +66,16 @@ def test_hrnet_stages_vs_reference_golden(name, prec):
     lrs, alphas = util.dev(g["lrs"]), util.dev(g["alphas"])
     with torch.no_grad():
         emb = m.encode_views(lrs)
-        assert tuple(emb.shape) == g["lrs"].shape + (64,)
-        _check(prec, util.nhwc_to_nchw(emb), g["emb"])
+        assert tuple(emb.shape[-5:]) == g["lrs"].shape + (64,)
+        _check(prec, util.nhwc_to_nchw(emb, prec), g["emb"])
         fused = m.fuse_views(emb, alphas)
-        _check(prec, util.nhwc_to_nchw(fused), g["fused"])
-        gf = torch.from_numpy(g["fused"]).cuda().permute(0, 2, 3, 1).contiguous().to(fused.dtype)
+        _check(prec, util.nhwc_to_nchw(fused, prec), g["fused"])
+        from hrnet_hip import binding
+        gf = binding.float_to_planes(torch.from_numpy(g["fused"]).cuda().permute(0, 2, 3, 1).contiguous(), m._dtype())
         _check(prec, m.decode_state(gf).cpu().numpy(), g["sr"])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 def test_hrnet_config1_shape(prec):
     """BASELINE config 1 (B=4, V=4, 128->384) against the reference's own output."""
     g = util.golden("hrnet_c1_b4_v4_s128")
@@ -78,7 +86,7 @@ def test_hrnet_config1_shape(prec):
     _check(prec, sr, g["sr"])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("shape", [(1, 2, 20), (3, 3, 8), (1, 7, 40), (2, 9, 33), (1, 16, 12), (1, 4, 72)])
 def test_hrnet_edge_shapes_vs_oracle(shape, prec):
     """Sizes that do not fill the 8x32 / 16x32 tiles, odd view counts, tiny images, and one image (72) that spans more than two
@@ -88,10 +96,7 @@ def test_hrnet_edge_shapes_vs_oracle(shape, prec):
     want = O.hrnet_forward(lrs, alphas, weights.hrnet_state(1234))
     with torch.no_grad():
         sr = util.hip_hrnet(prec)(util.dev(lrs), util.dev(alphas)).cpu().numpy()
-    if prec == "fp32":
-        assert util.rel_err(sr, want) <= FP32_GUARD
-    else:
-        _check(prec, sr, want)
+    _check(prec, sr, want)
 
 
 def test_general_conv_kernel_route_vs_reference_golden():
@@ -159,7 +164,7 @@ def test_packed_parameters_follow_updates():
 
 
 # ----------------------------------------------------------------------------- full-size properties (BASELINE configs 2/3)
-@pytest.mark.parametrize("prec,b,v", [("bf16", 32, 32), ("fp32", 16, 16)])
+@pytest.mark.parametrize("prec,b,v", [("bf16", 32, 32), ("fp32", 16, 16), ("bf16x3", 32, 32)])
 def test_full_size_properties(prec, b, v):
     """At the metric's size the oracle is too slow; check properties that must hold bit-exactly:
     determinism, batch independence (a sample alone == the sample inside the batch) and invariance to the content
@@ -231,9 +236,11 @@ def test_config5_image_size_fp32_vs_oracle():
     with torch.no_grad():
         got32 = util.hip_hrnet("fp32")(x, a).cpu().numpy()
         got16 = util.hip_hrnet("bf16")(x, a).cpu().numpy()
+        gotx3 = util.hip_hrnet("bf16x3")(x, a).cpu().numpy()
     assert got32.shape == want.shape == (1, 1, 1536, 1536)
     assert util.rel_err(got32, want) <= 1e-4
     _check("bf16", got16, want)
+    _check("bf16x3", gotx3, want)
 
 
 # ----------------------------------------------------------------------------- ShiftNet

@@ -54,8 +54,10 @@ def hip_shiftnet(seed=4321):
     return m.cuda().eval()
 
 
-def nhwc_to_nchw(t):
-    """(..., H, W, C) storage tensor -> float32 numpy (..., C, H, W)."""
+def nhwc_to_nchw(t, prec=None):
+    """(..., H, W, C) storage tensor -> float32 numpy (..., C, H, W); bf16x3 stage tensors are (2, ...) planes: hi + lo."""
+    if prec == "bf16x3":
+        t = t[0].float() + t[1].float()
     nd = t.dim()
     perm = list(range(nd - 3)) + [nd - 1, nd - 3, nd - 2]
     return t.float().permute(*perm).contiguous().cpu().numpy()
