@@ -81,28 +81,6 @@ def _check_config(config):
             "2->64 stem, 64-channel 3x3 convs, stride-3 k3 deconv, 1x1 final; got " + repr(config))
 
 
-class _HRNetTrainFunction(torch.autograd.Function):
-    """`srs = fusion_model(lrs, alphas)` ... `loss.backward()` (train.py:172-190) on the HIP kernels: hrn_hrnet_forward_train keeps
-    every intermediate in a workspace, hrn_hrnet_backward turns d_sr into the parameter gradients.  lrs / alphas get none."""
-
-    @staticmethod
-    def forward(ctx, module, names, lrs, alphas, *params):
-        packed = module._packed_f32()
-        sr, tws = binding.hrnet_forward_train(packed, lrs, alphas, module._num_layers, module.fuse.alpha_residual)
-        ctx.module, ctx.names, ctx.packed, ctx.tws = module, names, packed, tws
-        ctx.save_for_backward(lrs, alphas, *params)
-        return sr
-
-    @staticmethod
-    def backward(ctx, d_sr):
-        lrs, alphas, *params = ctx.saved_tensors
-        named = dict(zip(ctx.names, params))
-        grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in named.items()}
-        binding.hrnet_backward(ctx.packed, named, grads, ctx.module._num_layers, ctx.module.fuse.alpha_residual, lrs, alphas,
-                               d_sr.contiguous(), ctx.tws)          # ctx.tws stays: backward(retain_graph=True) may come again
-        return (None, None, None, None) + tuple(grads[k].to(named[k].dtype) for k in ctx.names)
-
-
 class _HRNetLazyTrainFunction(torch.autograd.Function):
     """`.train()` mode with `precision="bf16"`: the forward runs the bf16 INFERENCE kernels (what `precision` asks for; this is
     the path `src/predict.py` takes, whose `load_model` never calls `.eval()` and whose `get_sr_and_score` does not use
@@ -179,14 +157,21 @@ class HRNet(nn.Module):
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # .train() mode with grad enabled - the training loop (train.py:160-190), but also src/predict.py, which never calls
             # .eval() and uses no no_grad (predict.py:86-100, :17-49).  Autograd cannot tell us whether a backward pass will follow:
-            #   precision "fp32" (default): the fp32 training forward, which keeps its intermediates for the HIP backward (same
-            #                               numbers as the fp32 inference kernels);
+            #   precision "fp32" (default) / "bf16x3": the fp32 training forward (torch.ops.hrnet_hip.hrnet_forward_train), which keeps its
+            #                               intermediates for the HIP backward (same numbers as the fp32 inference kernels);
             #   precision "bf16":           the bf16 inference kernels, as asked for; a backward pass, if one comes, first
             #                               recomputes the forward on the fp32 training kernels (_HRNetLazyTrainFunction).
             # In .eval() mode (validation, train.py:196-215) the inference kernels run and the result carries no autograd graph.
             names = [k for k, _ in self.named_parameters()]
-            fn = _HRNetLazyTrainFunction if self._dtype() == binding.BF16 else _HRNetTrainFunction
-            return fn.apply(self, names, lrs.detach(), alphas.detach(), *[p for _, p in self.named_parameters()])
+            params = [p for _, p in self.named_parameters()]
+            if self._dtype() == binding.BF16:
+                return _HRNetLazyTrainFunction.apply(self, names, lrs.detach(), alphas.detach(), *params)
+            # the dispatcher-registered training op (binding.py): hrn_hrnet_forward_train with hrn_hrnet_backward as its autograd formula
+            if names != binding.hrnet_param_names(self._num_layers):
+                raise RuntimeError("HRNet parameters are not in the reference's registration order")
+            sr, _tws = torch.ops.hrnet_hip.hrnet_forward_train(self._packed_f32(), lrs.detach().float().contiguous(), alphas.detach().float().contiguous(),
+                                                               params, self._num_layers, bool(self.fuse.alpha_residual))
+            return sr
         packed, dt = self.packed_parameters()
         return torch.ops.hrnet_hip.hrnet_forward(packed, dt, self._num_layers, bool(self.fuse.alpha_residual), lrs.detach(), alphas.detach())
 

@@ -12,32 +12,6 @@ import lanczos
 from hrnet_hip import binding
 
 
-class _ShiftNetTrainFunction(torch.autograd.Function):
-    """`shifts = regis_model(pairs)` ... `loss.backward()` (train.py:40, :190) on the HIP kernels: hrn_shiftnet_forward_train
-    keeps each layer's pre-BatchNorm tensor and batch statistics; hrn_shiftnet_backward returns the gradients of every
-    parameter and of the input pairs (the SR crops come from HRNet, so the registration loss trains it too)."""
-
-    @staticmethod
-    def forward(ctx, module, names, mask, x, *params):
-        named = module._named()
-        theta, tws = binding.shiftnet_forward_train(module.packed_parameters(), named, x.detach(), momentum=module.layer1[1].momentum,
-                                                    dropout_mask=mask)
-        ctx.module, ctx.names, ctx.mask, ctx.tws = module, names, mask, tws
-        ctx.save_for_backward(x, *params)
-        return theta
-
-    @staticmethod
-    def backward(ctx, d_theta):
-        x, *params = ctx.saved_tensors
-        named = ctx.module._named()
-        for k, p in zip(ctx.names, params):
-            named[k] = p
-        grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in zip(ctx.names, params)}
-        d_x = binding.shiftnet_backward(named, grads, x.detach(), ctx.mask, d_theta.contiguous(), ctx.tws,
-                                        need_input_grad=ctx.needs_input_grad[3])
-        return (None, None, None, d_x) + tuple(grads[k] for k in ctx.names)
-
-
 class ShiftNet(nn.Module):
     def __init__(self, in_channel=1):
         super().__init__()
@@ -80,10 +54,18 @@ class ShiftNet(nn.Module):
         named = self._named()
         if self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training path: train-mode forward that keeps its intermediates + the HIP backward (parameters and input pairs)
-            names = [k for k, _ in self.named_parameters()]
-            theta = _ShiftNetTrainFunction.apply(self, names, mask, x, *[p for _, p in self.named_parameters()])
-            for i in range(1, 9):
-                getattr(self, f"layer{i}")[1].num_batches_tracked += 1
+            # the dispatcher-registered training op (binding.py): hrn_shiftnet_forward_train with hrn_shiftnet_backward as its autograd
+            # formula (parameters AND the input pairs: the SR crops come from HRNet, so the registration loss trains it too)
+            if [k for k, _ in self.named_parameters()] != binding.SHIFTNET_PARAM_NAMES:
+                raise RuntimeError("ShiftNet parameters are not in the reference's registration order")
+            buffers = [named[k] for k in binding.SHIFTNET_BUFFER_NAMES]
+            theta, _tws, new_running = torch.ops.hrnet_hip.shiftnet_forward_train(
+                self.packed_parameters(), x if x.dtype == torch.float32 else x.float(), [p for _, p in self.named_parameters()], buffers,
+                float(self.layer1[1].momentum), mask)
+            with torch.no_grad():
+                torch._foreach_copy_(buffers, new_running)
+                for i in range(1, 9):
+                    getattr(self, f"layer{i}")[1].num_batches_tracked += 1
             return theta
         theta = binding.shiftnet_forward(self.packed_parameters(), named, x.detach(), train_bn=self.training,
                                          momentum=self.layer1[1].momentum, dropout_mask=mask)

@@ -621,3 +621,203 @@ def _op_shift_cpsnr(srs: torch.Tensor, hrs: torch.Tensor, hr_maps: torch.Tensor,
 @_op_shift_cpsnr.register_fake
 def _(srs, hrs, hr_maps, border_w, clip):
     return srs.new_empty((srs.shape[0] if srs.dim() == 3 else 1,), dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------- the TRAINING entry points as dispatcher-registered ops
+# (call sites: src/train.py:174-191).  Each is registered with a fake (meta) implementation and, where the reference differentiates
+# through it, with `register_autograd`: the backward formula is itself a registered op over the C ABI's *_backward entry point.  The
+# reference-named modules call these through torch.ops.hrnet_hip.* in .train() mode.
+from typing import List, Optional, Sequence, Tuple  # noqa: E402
+
+
+def hrnet_param_names(num_layers):
+    """HRNet's parameters in the module's registration order (== the reference's state_dict order, HRNet.py:36-169)."""
+    names = ["encode.init_layer.0.weight", "encode.init_layer.0.bias", "encode.init_layer.1.weight"]
+    for l in range(num_layers):
+        names += [f"encode.res_layers.{l}.block.0.weight", f"encode.res_layers.{l}.block.0.bias", f"encode.res_layers.{l}.block.1.weight",
+                  f"encode.res_layers.{l}.block.2.weight", f"encode.res_layers.{l}.block.2.bias", f"encode.res_layers.{l}.block.3.weight"]
+    names += ["encode.final.0.weight", "encode.final.0.bias"]
+    names += ["fuse.fuse.0.block.0.weight", "fuse.fuse.0.block.0.bias", "fuse.fuse.0.block.1.weight",
+              "fuse.fuse.0.block.2.weight", "fuse.fuse.0.block.2.bias", "fuse.fuse.0.block.3.weight",
+              "fuse.fuse.1.weight", "fuse.fuse.1.bias", "fuse.fuse.2.weight"]
+    names += ["decode.deconv.0.weight", "decode.deconv.0.bias", "decode.deconv.1.weight", "decode.final.weight", "decode.final.bias"]
+    return names
+
+
+SHIFTNET_PARAM_NAMES = [f"layer{i}.{j}.{k}" for i in range(1, 9) for j in (0, 1) for k in ("weight", "bias")] + ["fc1.weight", "fc1.bias", "fc2.weight"]
+SHIFTNET_BUFFER_NAMES = [f"layer{i}.1.{k}" for i in range(1, 9) for k in ("running_mean", "running_var")]
+
+
+@torch.library.custom_op("hrnet_hip::hrnet_forward_train", mutates_args=(), device_types="cuda")
+def _op_hrnet_forward_train(packed: torch.Tensor, lrs: torch.Tensor, alphas: torch.Tensor, params: Sequence[torch.Tensor],
+                            num_layers: int, alpha_residual: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`srs = fusion_model(lrs, alphas)` in training (train.py:174): fp32 forward that keeps every intermediate in `tws`.  `packed` is the
+    F32 blob of `params` (the raw parameters travel along for the backward pass and as the differentiable inputs)."""
+    return hrnet_forward_train(packed, lrs, alphas, num_layers, alpha_residual)
+
+
+@_op_hrnet_forward_train.register_fake
+def _(packed, lrs, alphas, params, num_layers, alpha_residual):
+    b, v, h, w = lrs.shape
+    nbytes = load_library().hrn_hrnet_train_workspace_bytes(num_layers, b, v, h, w)
+    return lrs.new_empty((b, 1, 3 * h, 3 * w), dtype=torch.float32), lrs.new_empty((nbytes,), dtype=torch.uint8)
+
+
+@torch.library.custom_op("hrnet_hip::hrnet_backward", mutates_args=(), device_types="cuda")
+def _op_hrnet_backward(packed: torch.Tensor, params: Sequence[torch.Tensor], lrs: torch.Tensor, alphas: torch.Tensor, d_sr: torch.Tensor,
+                       tws: torch.Tensor, num_layers: int, alpha_residual: bool) -> List[torch.Tensor]:
+    """d_sr -> the gradient of every parameter (train.py:190 through HRNet), in `hrnet_param_names` order."""
+    names = hrnet_param_names(num_layers)
+    named = dict(zip(names, params))
+    grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in named.items()}
+    hrnet_backward(packed, named, grads, num_layers, alpha_residual, lrs, alphas, d_sr.contiguous(), tws)
+    return [grads[k] for k in names]
+
+
+@_op_hrnet_backward.register_fake
+def _(packed, params, lrs, alphas, d_sr, tws, num_layers, alpha_residual):
+    return [p.new_empty(p.shape, dtype=torch.float32) for p in params]
+
+
+def _hrnet_train_setup(ctx, inputs, output):
+    packed, lrs, alphas, params, num_layers, alpha_residual = inputs
+    ctx.num_layers, ctx.alpha_residual, ctx.n = num_layers, alpha_residual, len(params)
+    ctx.save_for_backward(packed, lrs, alphas, output[1], *params)
+
+
+def _hrnet_train_backward(ctx, d_sr, _d_tws):
+    packed, lrs, alphas, tws, *params = ctx.saved_tensors
+    grads = torch.ops.hrnet_hip.hrnet_backward(packed, params, lrs, alphas, d_sr, tws, ctx.num_layers, ctx.alpha_residual)
+    return None, None, None, [g.to(p.dtype) for g, p in zip(grads, params)], None, None
+
+
+_op_hrnet_forward_train.register_autograd(_hrnet_train_backward, setup_context=_hrnet_train_setup)
+
+
+def _shiftnet_named(params, buffers):
+    named = dict(zip(SHIFTNET_PARAM_NAMES, params))
+    named.update(zip(SHIFTNET_BUFFER_NAMES, buffers))
+    return named
+
+
+@torch.library.custom_op("hrnet_hip::shiftnet_forward_train", mutates_args=(), device_types="cuda")
+def _op_shiftnet_forward_train(packed: torch.Tensor, x: torch.Tensor, params: Sequence[torch.Tensor], bn_running: Sequence[torch.Tensor],
+                               momentum: float, dropout_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
+    """`shifts = regis_model(pairs)` in training (train.py:40): batch-statistics BatchNorm, the given dropout keep-mask; keeps each layer's
+    pre-BatchNorm tensor and statistics in `tws` for the backward.  Functional (an op with an autograd formula must be): the updated
+    running statistics come back as new tensors, in SHIFTNET_BUFFER_NAMES order, and the module copies them into its buffers."""
+    new_running = [b.clone() for b in bn_running]
+    theta, tws = shiftnet_forward_train(packed, _shiftnet_named(params, new_running), x, momentum=momentum, dropout_mask=dropout_mask)
+    return theta, tws, new_running
+
+
+@_op_shiftnet_forward_train.register_fake
+def _(packed, x, params, bn_running, momentum, dropout_mask):
+    nbytes = load_library().hrn_shiftnet_train_workspace_bytes(x.shape[0])
+    return x.new_empty((x.shape[0], 2), dtype=torch.float32), x.new_empty((nbytes,), dtype=torch.uint8), [b.new_empty(b.shape) for b in bn_running]
+
+
+@torch.library.custom_op("hrnet_hip::shiftnet_backward", mutates_args=(), device_types="cuda")
+def _op_shiftnet_backward(params: Sequence[torch.Tensor], x: torch.Tensor,
+                          dropout_mask: Optional[torch.Tensor], d_theta: torch.Tensor, tws: torch.Tensor,
+                          need_input_grad: bool) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    """d_theta -> (parameter gradients in SHIFTNET_PARAM_NAMES order, d_x (empty when not needed)).  The batch statistics the backward
+    needs are in `tws`; the running statistics take no part (the BatchNorm weights stand in for them in the C struct)."""
+    named = dict(zip(SHIFTNET_PARAM_NAMES, params))
+    for k in SHIFTNET_BUFFER_NAMES:
+        named[k] = named[k.rsplit(".", 1)[0] + ".weight"]
+    grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in zip(SHIFTNET_PARAM_NAMES, params)}
+    d_x = shiftnet_backward(named, grads, x, dropout_mask, d_theta.contiguous(), tws, need_input_grad=need_input_grad)
+    return [grads[k] for k in SHIFTNET_PARAM_NAMES], (d_x if d_x is not None else x.new_empty((0,)))
+
+
+@_op_shiftnet_backward.register_fake
+def _(params, x, dropout_mask, d_theta, tws, need_input_grad):
+    return [p.new_empty(p.shape, dtype=torch.float32) for p in params], (x.new_empty(x.shape) if need_input_grad else x.new_empty((0,)))
+
+
+def _shiftnet_train_setup(ctx, inputs, output):
+    packed, x, params, bn_running, momentum, dropout_mask = inputs
+    ctx.np, ctx.has_mask = len(params), dropout_mask is not None
+    ctx.save_for_backward(x, output[1], *params, *([dropout_mask] if dropout_mask is not None else []))
+
+
+def _shiftnet_train_backward(ctx, d_theta, _d_tws, _d_running):
+    x, tws, *rest = ctx.saved_tensors
+    params = rest[:ctx.np]
+    mask = rest[ctx.np] if ctx.has_mask else None
+    need_x = ctx.needs_input_grad[1]
+    grads, d_x = torch.ops.hrnet_hip.shiftnet_backward(params, x, mask, d_theta, tws, need_x)
+    return None, (d_x if need_x else None), grads, [None] * len(SHIFTNET_BUFFER_NAMES), None, None
+
+
+_op_shiftnet_forward_train.register_autograd(_shiftnet_train_backward, setup_context=_shiftnet_train_setup)
+
+
+@torch.library.custom_op("hrnet_hip::lanczos_shift_backward", mutates_args=(), device_types="cuda")
+def _op_lanczos_shift_backward(img: torch.Tensor, shift: torch.Tensor, d_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Adjoint of lanczos_shift wrt the image and the gradient wrt the shifts (through the 7 taps per axis): (d_img, d_shift (c, 2))."""
+    d_img, d_shift = lanczos_shift_backward(img, shift, d_out.contiguous(), True, True)
+    full = torch.zeros_like(shift, dtype=torch.float32)
+    full[:d_shift.shape[0]] = d_shift                       # `shift` may carry more rows than img has channels
+    return d_img, full
+
+
+@_op_lanczos_shift_backward.register_fake
+def _(img, shift, d_out):
+    return img.new_empty(img.shape, dtype=torch.float32), shift.new_empty(shift.shape, dtype=torch.float32)
+
+
+def _lanczos_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _lanczos_backward(ctx, d_out):
+    img, shift = ctx.saved_tensors
+    d_img, d_shift = torch.ops.hrnet_hip.lanczos_shift_backward(img, shift, d_out)
+    return (d_img.to(img.dtype) if ctx.needs_input_grad[0] else None), (d_shift.to(shift.dtype) if ctx.needs_input_grad[1] else None)
+
+
+_op_lanczos_shift.register_autograd(_lanczos_backward, setup_context=_lanczos_setup)
+
+
+@torch.library.custom_op("hrnet_hip::get_loss_train", mutates_args=(), device_types="cuda")
+def _op_get_loss_train(srs: torch.Tensor, hrs: torch.Tensor, hr_maps: torch.Tensor, metric: str, crop: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The registered-loss tail (train.py:78-87, :183-187): (loss per sample (B,), stats (B,4) f64 = {n, bias, cMSE, 0})."""
+    return get_loss_train(srs, hrs, hr_maps, metric, crop)
+
+
+@_op_get_loss_train.register_fake
+def _(srs, hrs, hr_maps, metric, crop):
+    return srs.new_empty((srs.shape[0],), dtype=torch.float32), srs.new_empty((srs.shape[0], 4), dtype=torch.float64)
+
+
+@torch.library.custom_op("hrnet_hip::get_loss_backward", mutates_args=(), device_types="cuda")
+def _op_get_loss_backward(srs: torch.Tensor, hrs: torch.Tensor, hr_maps: torch.Tensor, stats: torch.Tensor, d_out: torch.Tensor,
+                          metric: str, crop: int) -> torch.Tensor:
+    return get_loss_backward(srs, hrs, hr_maps, stats, d_out.contiguous(), metric, crop)
+
+
+@_op_get_loss_backward.register_fake
+def _(srs, hrs, hr_maps, stats, d_out, metric, crop):
+    return srs.new_empty(srs.shape, dtype=torch.float32)
+
+
+def _loss_setup(ctx, inputs, output):
+    srs, hrs, hr_maps, ctx.metric, ctx.crop = inputs
+    ctx.save_for_backward(srs, hrs, hr_maps, output[1])
+
+
+def _loss_backward(ctx, d_out, _d_stats):
+    srs, hrs, hr_maps, stats = ctx.saved_tensors
+    return torch.ops.hrnet_hip.get_loss_backward(srs, hrs, hr_maps, stats, d_out, ctx.metric, ctx.crop), None, None, None, None
+
+
+_op_get_loss_train.register_autograd(_loss_backward, setup_context=_loss_setup)
+
+
+@torch.library.custom_op("hrnet_hip::adam_step", mutates_args=("params", "exp_avg", "exp_avg_sq"), device_types="cuda")
+def _op_adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr: float, beta1: float,
+                  beta2: float, eps: float, weight_decay: float, step: int) -> None:
+    """`optimizer.step()` of torch.optim.Adam (train.py:191) on one flat fp32 buffer, in place."""
+    adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step)

@@ -22,9 +22,6 @@
 #ifndef V6_RES_NT
 #define V6_RES_NT 1         // residual loads non-temporal (read once; A/B -0.6 %)
 #endif
-#ifndef V6X3_AHEAD
-#define V6X3_AHEAD 1      // X3, COUT = 128: residual rounds (both planes: 32 registers) in flight ahead of the one being consumed
-#endif
 #ifndef V6_BAL
 #define V6_BAL 4          // COUT = 128: eighths of a stage's steps during which waves 4-7 run at raised priority (0 = off; COUT = 64
                           // runs without: A/B on one box, 0.454 vs 0.463 ms)
@@ -58,7 +55,11 @@ template <int COUT, bool X3 = false> struct G6 {
     static constexpr int LB = NCB * 2;                     // bytes of a pixel's row one lane holds: its NCB channels NCB*c15 .. +NCB-1
     static constexpr int OFF_FIFO = OFF_BIAS + 512;        // 4 KB per wave: round 0 of the residual, fetched by LDS-DMA under the last stage
     static constexpr int FIFO_WAVE = (LB == 16 && !X3) ? 4096 : 0;
-    static constexpr int LDS_BYTES = OFF_FIFO + 8 * FIFO_WAVE;
+    // X3: the tile's halo offsets (5 per lane) live in LDS instead of registers, 1,280 B per wave (they are what hipcc spills first when
+    // the epilogue's two residual planes push the kernel over 256 registers, and a spilled offset is reloaded in the main loop behind a
+    // vmcnt(0) that drains the DMAs in flight: measured 2.62 against 1.97 ms for the layer without residual)
+    static constexpr int OFF_HOFF = OFF_FIFO + 8 * FIFO_WAVE;
+    static constexpr int LDS_BYTES = OFF_HOFF + (X3 ? 8 * 5 * 256 : 0);
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr6;
@@ -156,16 +157,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
             const int py = pix / HW6, px = pix - py * HW6;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             const bool ok = pix < NPIX6 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            hoff[jj] = ok ? (unsigned)(gy * W + gx) * in_pitch + (unsigned)(lc * 16) : OOB6;
+            const unsigned ho = ok ? (unsigned)(gy * W + gx) * in_pitch + (unsigned)(lc * 16) : OOB6;
+            if constexpr (X3) *(unsigned*)(smem + GEO::OFF_HOFF + (w * 5 + jj) * 256 + lq * 4) = ho;
+            else hoff[jj] = ho;
         }
     };
     // one halo piece: chunk c (32 channels = 64 bytes of a pixel) of the image behind `rs` -> input buffer `buf`
-    auto dma_halo = [&](__amdgpu_buffer_rsrc_t rs, int c, int buf, int jj) __attribute__((always_inline)) {
+    auto dma_halo_v = [&](__amdgpu_buffer_rsrc_t rs, int c, int buf, int jj, unsigned voff) __attribute__((always_inline)) {
         const int j = w + 8 * jj;
         if (j < N_IN6) {
             const unsigned soff = in_pair ? (unsigned)((c & 1) * 64) : (unsigned)(c * 64);
-            if (!(V6_ABL & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr6)(smem + OFF_IN + buf * IN_BYTES6 + j * 1024), 16, hoff[jj], soff, 0, 0);
+            if (!(V6_ABL & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr6)(smem + OFF_IN + buf * IN_BYTES6 + j * 1024), 16, voff, soff, 0, 0);
         }
+    };
+    auto hoff_lds = [&](int jj) __attribute__((always_inline)) -> unsigned {     // X3: this lane's offset of piece jj of the tile
+        return *(const unsigned*)(smem + GEO::OFF_HOFF + (w * 5 + jj) * 256 + lane * 4);
+    };
+    auto dma_halo = [&](__amdgpu_buffer_rsrc_t rs, int c, int buf, int jj) __attribute__((always_inline)) {
+        if constexpr (X3) dma_halo_v(rs, c, buf, jj, hoff_lds(jj));
+        else dma_halo_v(rs, c, buf, jj, hoff[jj]);
     };
     // one weight piece of stage (c, tg): piece qq = (tap kx = qq / NCB, cout block jb = qq % NCB): 16 couts x 64 bytes;
     // lane i -> row i >> 2 of the block = cout NCB * (i >> 2) + jb (the interleave that makes a lane's accumulators a contiguous
@@ -339,14 +349,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                 const bool nlo = X3 && ps == 0;
                 const int cn = nlo ? c : (c + 1) & (NCH - 1);
                 const int nbuf = X3 ? (nlo ? 1 : 0) : (cn & 1);
-                const size_t hb = ((in_pair && cn >= 2) ? inB : inA) + (nlo ? src_lo : (size_t)0);      // in the tile's last pass these already are the next tile's views
+                size_t hb = ((in_pair && cn >= 2) ? inB : inA) + (nlo ? src_lo : (size_t)0);      // in the tile's last pass these already are the next tile's views
+                if constexpr (X3) {
+                    // (the image bases are wave-uniform, but where hipcc keeps them in vector registers it wraps every DMA of the stage in a
+                    // waterfall loop: say so - CDNA guide T20)
+                    hb = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb) |
+                         ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hb >> 32)) << 32);      // (the builtin returns a signed int)
+                }
                 const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(src0 + hb), 0, (int)img_bytes, 0x00020000);
                 // DMA item `it` of this stage, issued from the gap behind the it-th step: weights of stage s+1 first, then (tg 0: pieces
                 // jj 0-2, tg 1: pieces 3-4) of the next halo chunk
+                // X3: the offsets of the pieces this stage issues come from LDS, read here - nothing else of the wave is in flight on the LDS
+                // queue right behind the stage barrier - and waited for at once, so that no wait lands in the fragment stream
+                unsigned hst[3] = {0u, 0u, 0u};
+                if constexpr (X3) {
+                    if (tg < 2 && next_chunk) {
+#pragma unroll
+                        for (int k = 0; k < (tg == 0 ? 3 : 2); ++k) hst[k] = hoff_lds(tg == 0 ? k : 3 + k);
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hst[0]), "+v"(hst[1]), "+v"(hst[2]));
+                    }
+                }
                 auto issue_item = [&](int it) __attribute__((always_inline)) {
                     if (it < NW3) { if (have_next) dma_w(c2, tg2, slot_r ^ 1, it, wpl2); }
-                    else if (tg == 0 && it < NW3 + 3) { if (next_chunk) dma_halo(rs_h, cn, nbuf, it - NW3); }
-                    else if (tg == 1 && it < NW3 + 2) { if (next_chunk) dma_halo(rs_h, cn, nbuf, it - NW3 + 3); }
+                    else if (tg == 0 && it < NW3 + 3) {
+                        if (next_chunk) { if constexpr (X3) dma_halo_v(rs_h, cn, nbuf, it - NW3, hst[it - NW3]); else dma_halo(rs_h, cn, nbuf, it - NW3); }
+                    } else if (tg == 1 && it < NW3 + 2) {
+                        if (next_chunk) { if constexpr (X3) dma_halo_v(rs_h, cn, nbuf, it - NW3 + 3, hst[it - NW3]); else dma_halo(rs_h, cn, nbuf, it - NW3 + 3); }
+                    }
                 };
                 constexpr int N_ITEMS = NW3 + (tg == 0 ? 3 : tg == 1 ? 2 : 0);
                 static_assert(N_ITEMS <= NSTEP, "one DMA item per step");
@@ -435,25 +464,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                     int le = lane;
                     asm volatile("" : "+v"(le));
                     const int c15e = le & 15, qe = le >> 4;
-                    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, (int)(hw * ROW), 0x00020000);
-                    const __amdgpu_buffer_rsrc_t rs_out_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(outp + p.out_lo), 0, (int)(hw * ROW), 0x00020000);
+                    // (wave-uniform, but hipcc may hold the output base in vector registers and then wraps every store in a waterfall loop)
+                    const size_t ob_ = (size_t)outp;
+                    unsigned char* const outu = (unsigned char*)((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob_) |
+                                                                 ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ob_ >> 32)) << 32));
+                    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)outu, 0, (int)(hw * ROW), 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rs_out_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(outu + p.out_lo), 0, (int)(hw * ROW), 0x00020000);
                     const size_t res_lo_off = RESM == 2 ? p.stack_lo : p.res_lo;
                     lane_row_t rq[8][4];                                                      // [plane * 4 + round][j]
-                    auto res_load = [&](int r) __attribute__((always_inline)) {              // both planes of round r
+                    auto res_load = [&](int r, int pl) __attribute__((always_inline)) {      // plane pl of round r
 #pragma unroll
-                        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                rq[pl * 4 + r][j] = __builtin_nontemporal_load((const lane_row_t*)(res_src(r, j) + (pl ? res_lo_off : (size_t)0)));
+                        for (int j = 0; j < 4; ++j)
+                            rq[pl * 4 + r][j] = __builtin_nontemporal_load((const lane_row_t*)(res_src(r, j) + (pl ? res_lo_off : (size_t)0)));
                     };
-                    // rounds in flight ahead of the one being consumed: 2 where a lane's share of a row is 8 bytes, 1 where it is 16
-                    constexpr int AHEAD = LB == 16 ? V6X3_AHEAD : 2;
-                    if (RES) { res_load(0); if (AHEAD == 2) res_load(1); }
+                    // Residual schedule.  COUT = 64 (a lane's share of a row is 8 bytes): both planes of a round two rounds ahead.  COUT = 128
+                    // (16 bytes: a round is 32 registers beside the 128 accumulators): round 0 and the hi plane of round 1 up front, and as
+                    // the rounds retire their accumulators the prefetch deepens (lo 1 + round 2 behind round 0, round 3 behind round 1).
+                    if (RES) {
+                        res_load(0, 0); res_load(0, 1); res_load(1, 0);
+                        if (LB == 8) res_load(1, 1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);               // (hipcc would otherwise start every round's loads here and spill them)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int gy = y0 + 2 * w + (r >> 1);
-                        if (RES && r + AHEAD < 4) { res_load(r + AHEAD); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             lane_row_t oh, ol;
@@ -482,6 +516,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                                 __builtin_amdgcn_raw_buffer_store_b64(oh, rs_out, voff, 0, V6_ST_AUX);
                                 __builtin_amdgcn_raw_buffer_store_b64(ol, rs_out_lo, voff, 0, V6_ST_AUX);
                             }
+                        }
+                        if (RES) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (LB == 16) {
+                                if (r == 0) { res_load(1, 1); res_load(2, 0); res_load(2, 1); }
+                                if (r == 1) { res_load(3, 0); res_load(3, 1); }
+                            } else if (r < 2) { res_load(r + 2, 0); res_load(r + 2, 1); }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }

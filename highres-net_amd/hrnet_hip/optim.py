@@ -154,5 +154,6 @@ class FusedAdam(torch.optim.Optimizer):
             self._rebind(f)
             f["step"] += 1
             b1, b2 = group["betas"]
-            binding.adam_step(f["p"], f["g"], f["m"], f["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], f["step"])
+            torch.ops.hrnet_hip.adam_step(f["p"], f["g"], f["m"], f["v"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                          float(group["weight_decay"]), int(f["step"]))
         return loss

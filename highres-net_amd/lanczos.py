@@ -30,31 +30,10 @@ def lanczos_shift(img, shift, p=3, a=3, N=7):
         raise ValueError(f"padding p={p} must cover the kernel radius {N // 2}")
     if min(img.shape[-2:]) <= p:
         raise ValueError("reflection padding needs p < H, W")       # same condition nn.ReflectionPad2d enforces
-    if torch.is_grad_enabled() and ((torch.is_tensor(img) and img.requires_grad) or (torch.is_tensor(shift) and shift.requires_grad)):
-        out = _LanczosShiftFunction.apply(img, shift)          # differentiable wrt the image and the shifts (apply_shifts)
+    if torch.is_tensor(img) and torch.is_tensor(shift) and img.is_cuda and shift.is_cuda:
+        # dispatcher-registered op, differentiable wrt the image and the shifts (apply_shifts, train.py:47-63): its autograd formula is
+        # torch.ops.hrnet_hip.lanczos_shift_backward (adjoint of the shift + the gradient through the 7 taps per axis)
+        out = torch.ops.hrnet_hip.lanczos_shift(img if img.dtype == torch.float32 else img.float(), shift if shift.dtype == torch.float32 else shift.float())
     else:
-        out = torch.ops.hrnet_hip.lanczos_shift(img, shift) if img.is_cuda and shift.is_cuda else binding.lanczos_shift(img, shift)
+        out = binding.lanczos_shift(img, shift)                 # raises: no CPU fallback
     return out if img.dtype == torch.float32 else out.to(img.dtype)
-
-
-class _LanczosShiftFunction(torch.autograd.Function):
-    """lanczos_shift with the HIP backward: d img = adjoint of the shift, d shift = gradient through the 7 taps per axis
-    (the reference gets both from torch autograd over lanczos.py:5-107)."""
-
-    @staticmethod
-    def forward(ctx, img, shift):
-        ctx.save_for_backward(img, shift)
-        return binding.lanczos_shift(img, shift)
-
-    @staticmethod
-    def backward(ctx, d_out):
-        img, shift = ctx.saved_tensors
-        need_img, need_shift = ctx.needs_input_grad
-        d_img, d_shift = binding.lanczos_shift_backward(img, shift, d_out.contiguous(), need_img, need_shift)
-        if d_img is not None and d_img.dtype != img.dtype:
-            d_img = d_img.to(img.dtype)
-        if d_shift is not None:
-            full = torch.zeros_like(shift, dtype=torch.float32)
-            full[:d_shift.shape[0]] = d_shift                   # shift may carry more rows than img has channels
-            d_shift = full.to(shift.dtype)
-        return d_img, d_shift

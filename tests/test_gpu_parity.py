@@ -360,9 +360,10 @@ def test_bf16_kernels_on_awkward_sizes_vs_fp32_path(S, V):
 
 
 def test_entry_points_are_registered_torch_ops():
-    """north_star: "exposed to Python as PyTorch-ROCm custom ops".  The inference entry points are dispatcher-registered
-    (torch.ops.hrnet_hip.*) with fake implementations: callable through torch.ops, shape-inferable on the meta device, and the
-    eval-mode module goes through them."""
+    """north_star: "exposed to Python as PyTorch-ROCm custom ops".  Inference AND training entry points are dispatcher-registered
+    (torch.ops.hrnet_hip.*) with fake implementations and - where train.py differentiates through them - autograd formulas that are
+    registered ops themselves: callable through torch.ops, shape-inferable on the meta device, `torch.library.opcheck` clean, and the
+    modules go through them in both modes."""
     from hrnet_hip import binding
     lrs, alphas = synth.fast_batch(5, 2, 4, 32)
     m = util.hip_hrnet("fp32")
@@ -374,7 +375,50 @@ def test_entry_points_are_registered_torch_ops():
         img = torch.rand(1, 3, 40, 40, device="cuda")
         sh = torch.tensor([[0.3, -0.2], [0.0, 0.0], [1.5, 0.25]], device="cuda")
         assert torch.equal(torch.ops.hrnet_hip.lanczos_shift(img, sh), binding.lanczos_shift(img, sh))
-    assert torch.library.opcheck(torch.ops.hrnet_hip.lanczos_shift.default, (img, sh), test_utils=("test_schema", "test_faketensor")) is not None
+    basic = ("test_schema", "test_faketensor")
+    full = ("test_schema", "test_faketensor", "test_autograd_registration")
+    ops = torch.ops.hrnet_hip
+    for name in ("hrnet_forward", "lanczos_shift", "lanczos_kernel", "shift_cpsnr", "hrnet_forward_train", "hrnet_backward",
+                 "shiftnet_forward_train", "shiftnet_backward", "lanczos_shift_backward", "get_loss_train", "get_loss_backward", "adam_step"):
+        assert hasattr(ops, name), name
+    torch.library.opcheck(ops.lanczos_shift.default, (img.clone().requires_grad_(True), sh.clone().requires_grad_(True)), test_utils=full)
+    torch.library.opcheck(ops.lanczos_shift_backward.default, (img, sh, torch.rand_like(img)), test_utils=basic)
+    # HRNet training pair
+    mt = util.hip_hrnet("fp32", seed=77).train()
+    params = [p for _, p in mt.named_parameters()]
+    p32 = mt._packed_f32()
+    torch.library.opcheck(ops.hrnet_forward_train.default, (p32, x, a, params, 2, True), test_utils=full)
+    sr, tws = ops.hrnet_forward_train(p32, x, a, params, 2, True)
+    torch.library.opcheck(ops.hrnet_backward.default, (p32, [p.detach() for p in params], x, a, torch.rand_like(sr), tws, 2, True), test_utils=basic)
+    mt.eval()
+    # ShiftNet training pair
+    from DeepNetworks.ShiftNet import ShiftNet
+    sn = ShiftNet().cuda().train()
+    with torch.no_grad():
+        sn.fc2.weight.normal_(0.0, 1e-3)
+    named = sn._named()
+    sp = [named[k] for k in binding.SHIFTNET_PARAM_NAMES]
+    sb = [named[k] for k in binding.SHIFTNET_BUFFER_NAMES]
+    pairs = torch.rand(2, 2, 128, 128, device="cuda")
+    mask = (torch.rand(2, 32768, device="cuda") >= 0.5).to(torch.uint8)
+    before = [b.clone() for b in sb]
+    torch.library.opcheck(ops.shiftnet_forward_train.default, (sn.packed_parameters(), pairs.clone().requires_grad_(True), sp, sb, 0.1, mask), test_utils=full)
+    assert all(torch.equal(b0, b1) for b0, b1 in zip(before, sb))                    # functional: the op itself leaves the buffers alone
+    theta, stws, new_running = ops.shiftnet_forward_train(sn.packed_parameters(), pairs, sp, sb, 0.1, mask)
+    assert not torch.equal(new_running[0], sb[0])
+    torch.library.opcheck(ops.shiftnet_backward.default, ([p.detach() for p in sp], pairs, mask, torch.rand_like(theta), stws, True), test_utils=basic)
+    theta_mod = sn(pairs)                                                             # the module copies the new statistics into its buffers
+    assert theta_mod.requires_grad and int(sn.layer1[1].num_batches_tracked) == 1 and not torch.equal(before[0], sn.layer1[1].running_mean)
+    # registered loss
+    srs, hrs = torch.rand(2, 48, 48, device="cuda"), torch.rand(2, 48, 48, device="cuda")
+    maps = (torch.rand(2, 48, 48, device="cuda") > 0.2).float()
+    torch.library.opcheck(ops.get_loss_train.default, (srs.clone().requires_grad_(True), hrs, maps, "cPSNR", 3), test_utils=full)
+    out, stats = ops.get_loss_train(srs, hrs, maps, "cPSNR", 3)
+    torch.library.opcheck(ops.get_loss_backward.default, (srs, hrs, maps, stats, torch.rand_like(out), "cPSNR", 3), test_utils=basic)
+    # fused Adam (mutates its flat buffers)
+    n = 4096
+    pbuf, g, m1, v1 = torch.rand(n, device="cuda"), torch.rand(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    torch.library.opcheck(ops.adam_step.default, (pbuf, g, m1, v1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1), test_utils=basic)
 
 
 def test_forward_is_graph_capturable():
