@@ -663,7 +663,7 @@ def _(packed, lrs, alphas, params, num_layers, alpha_residual):
     return lrs.new_empty((b, 1, 3 * h, 3 * w), dtype=torch.float32), lrs.new_empty((nbytes,), dtype=torch.uint8)
 
 
-@torch.library.custom_op("hrnet_hip::hrnet_backward", mutates_args=(), device_types="cuda")
+@torch.library.custom_op("hrnet_hip::hrnet_backward", mutates_args=("tws",), device_types="cuda")     # (tws also holds the backward's scratch buffers)
 def _op_hrnet_backward(packed: torch.Tensor, params: Sequence[torch.Tensor], lrs: torch.Tensor, alphas: torch.Tensor, d_sr: torch.Tensor,
                        tws: torch.Tensor, num_layers: int, alpha_residual: bool) -> List[torch.Tensor]:
     """d_sr -> the gradient of every parameter (train.py:190 through HRNet), in `hrnet_param_names` order."""
@@ -687,7 +687,9 @@ def _hrnet_train_setup(ctx, inputs, output):
 
 def _hrnet_train_backward(ctx, d_sr, _d_tws):
     packed, lrs, alphas, tws, *params = ctx.saved_tensors
-    grads = torch.ops.hrnet_hip.hrnet_backward(packed, params, lrs, alphas, d_sr, tws, ctx.num_layers, ctx.alpha_residual)
+    # (tws.data: the backward's scratch buffers live in tws too, so the op declares it mutated; through an alias with its own version
+    # counter the saved tensor stays valid for a second backward pass - backward(retain_graph=True), the kept intermediates are only read)
+    grads = torch.ops.hrnet_hip.hrnet_backward(packed, params, lrs, alphas, d_sr, tws.data, ctx.num_layers, ctx.alpha_residual)
     return None, None, None, [g.to(p.dtype) for g, p in zip(grads, params)], None, None
 
 
@@ -717,7 +719,7 @@ def _(packed, x, params, bn_running, momentum, dropout_mask):
     return x.new_empty((x.shape[0], 2), dtype=torch.float32), x.new_empty((nbytes,), dtype=torch.uint8), [b.new_empty(b.shape) for b in bn_running]
 
 
-@torch.library.custom_op("hrnet_hip::shiftnet_backward", mutates_args=(), device_types="cuda")
+@torch.library.custom_op("hrnet_hip::shiftnet_backward", mutates_args=("tws",), device_types="cuda")  # (tws also holds the backward's scratch buffers)
 def _op_shiftnet_backward(params: Sequence[torch.Tensor], x: torch.Tensor,
                           dropout_mask: Optional[torch.Tensor], d_theta: torch.Tensor, tws: torch.Tensor,
                           need_input_grad: bool) -> Tuple[List[torch.Tensor], torch.Tensor]:
@@ -747,7 +749,7 @@ def _shiftnet_train_backward(ctx, d_theta, _d_tws, _d_running):
     params = rest[:ctx.np]
     mask = rest[ctx.np] if ctx.has_mask else None
     need_x = ctx.needs_input_grad[1]
-    grads, d_x = torch.ops.hrnet_hip.shiftnet_backward(params, x, mask, d_theta, tws, need_x)
+    grads, d_x = torch.ops.hrnet_hip.shiftnet_backward(params, x, mask, d_theta, tws.data, need_x)      # (tws.data: see _hrnet_train_backward)
     return None, (d_x if need_x else None), grads, [None] * len(SHIFTNET_BUFFER_NAMES), None, None
 
 
