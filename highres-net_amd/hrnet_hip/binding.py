@@ -357,14 +357,14 @@ def shiftnet_pack(named):
 
 def shiftnet_forward(packed, named, x, train_bn=False, momentum=0.1, dropout_mask=None):
     """x (B,2,128,128) -> theta (B,2).  `named` supplies the live BatchNorm tensors (running stats are updated in
-    place when train_bn).  dropout_mask: None or uint8 (B,32768) keep-mask in the reference's flatten order."""
+    place when train_bn) and fc1.weight, which the kernel reads in place.  dropout_mask: None or uint8 (B,32768) keep-mask in the reference's flatten order."""
     lib = load_library()
     x = _dev_f32(x, "x")
     if x.dim() != 4 or tuple(x.shape[1:]) != (2, 128, 128):
         raise ValueError(f"ShiftNet input must be (B,2,128,128) (fc1 is hard-wired to 128*16*16, ShiftNet.py:44); got {tuple(x.shape)}")
     B = x.shape[0]
     keep = []
-    P = _shiftnet_struct(named, keep, False)
+    P = _shiftnet_struct(named, keep, True)        # (fc1.weight is read in place by the kernel: not part of `packed`)
     mptr = ctypes.c_void_p(0)
     if dropout_mask is not None:
         if dropout_mask.dtype != torch.uint8 or tuple(dropout_mask.shape) != (B, 32768) or not dropout_mask.is_cuda:
@@ -399,7 +399,7 @@ def shiftnet_forward_train(packed, named, x, momentum=0.1, dropout_mask=None):
     mptr, dropout_mask = _check_shiftnet_input(x, dropout_mask)
     B = x.shape[0]
     keep = []
-    P = _shiftnet_struct(named, keep, False)
+    P = _shiftnet_struct(named, keep, True)        # (fc1.weight is read in place by the kernel: not part of `packed`)
     nbytes = lib.hrn_shiftnet_train_workspace_bytes(B)
     tws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     theta = torch.empty((B, 2), dtype=torch.float32, device=x.device)

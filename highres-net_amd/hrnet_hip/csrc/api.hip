@@ -135,7 +135,7 @@ int decoder_impl(const void* pk, int dt, int nl, const void* fused, int N, int H
 
 // ---------------------------------------------------------------- ShiftNet layouts (packed parameters: shiftnet_layout.h)
 struct SnWs {
-    size_t means, scale, shift, partial, x, y, fc, total;
+    size_t means, scale, shift, partial, x, y, fc, xr, fc_partial, total;
 };
 SnWs sn_ws(int B) {
     SnWs w;
@@ -147,6 +147,8 @@ SnWs sn_ws(int B) {
     w.x = take((size_t)B * 128 * 128 * 64 * 4);     // conv output (pre-BN), largest at layer 1/2
     w.y = take((size_t)B * 128 * 128 * 64 * 4);     // activation after BN+ReLU(+pool)
     w.fc = take((size_t)B * 1024 * 4);
+    w.xr = take((size_t)B * 32768 * 4);             // fc1's input in the reference's flatten order
+    w.fc_partial = take(hrn_fc1_partial_bytes());
     w.total = off;
     return w;
 }
@@ -264,8 +266,7 @@ int hrn_shiftnet_pack(const hrn_shiftnet_params* P, void* packed, size_t packed_
         }
         HRN_HIP(hipMemcpyAsync(at(packed, L.conv_b[i]), P->conv_b[i], SN_CO[i] * 4, hipMemcpyDeviceToDevice, s));
     }
-    HRN_CHECK(P->fc1_w && P->fc1_b && P->fc2_w, -2, "hrn_shiftnet_pack: null fc parameter");
-    if ((rc = hrn_launch_fc1_pack(P->fc1_w, (float*)at(packed, L.fc1_w), s))) return rc;
+    HRN_CHECK(P->fc1_b && P->fc2_w, -2, "hrn_shiftnet_pack: null fc parameter");
     HRN_HIP(hipMemcpyAsync(at(packed, L.fc1_b), P->fc1_b, 1024 * 4, hipMemcpyDeviceToDevice, s));
     HRN_HIP(hipMemcpyAsync(at(packed, L.fc2_w), P->fc2_w, 2 * 1024 * 4, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -276,6 +277,7 @@ size_t hrn_shiftnet_workspace_bytes(int B) { return B > 0 ? sn_ws(B).total : 0; 
 int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* P, const float* x, int B, int train_bn, float momentum,
                          const unsigned char* dropout_mask, float* theta, void* ws, size_t ws_bytes, void* stream) {
     HRN_CHECK(packed && P && x && theta && ws, -2, "hrn_shiftnet_forward: null argument");
+    HRN_CHECK(P->fc1_w, -2, "hrn_shiftnet_forward: params->fc1_w is null (fc1.weight is read in place)");
     HRN_CHECK(B > 0, -2, "hrn_shiftnet_forward: empty batch");
     const SnLayout L = sn_layout();
     const SnWs wl = sn_ws(B);
@@ -293,6 +295,24 @@ int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* P, const
     if ((rc = hrn_launch_plane_mean(x, means, B * 2, plane, s))) return rc;                      // ShiftNet.py:58
     for (int i = 0; i < 8; ++i) {
         HRN_CHECK(P->bn_g[i] && P->bn_b[i] && P->bn_rm[i] && P->bn_rv[i], -2, "hrn_shiftnet_forward: null BatchNorm tensor %d", i);
+        const int C = SN_CO[i];
+        if (i > 0 && !train_bn) {
+            // eval mode: BatchNorm (running statistics) + ReLU are the convolution's epilogue - one launch per layer instead of three and
+            // no pre-BatchNorm tensor; the pooled layers keep a pool-only pass                         ShiftNet.py:16-42 in .eval()
+            if ((rc = hrn_launch_bn_fold(P->bn_g[i], P->bn_b[i], P->bn_rm[i], P->bn_rv[i], 1e-5f, (const float*)at(packed, L.conv_b[i]),
+                                         scale, shift, C, s))) return rc;
+            ConvParams p = conv_base(B, hsz, hsz);
+            p.in = by; p.out = bx;
+            p.wpk = at(packed, L.conv_w[i]); p.scale = scale; p.bias = shift; p.relu = 1;
+            if ((rc = hrn_launch_conv3x3(HRN_F32, SN_CI[i], C, p, s))) return rc;
+            if (SN_POOL[i]) {
+                if ((rc = hrn_launch_bn_act_pool(bx, nullptr, nullptr, by, B, hsz, hsz, C, 1, s))) return rc;
+                hsz /= 2;
+            } else {
+                float* t = bx; bx = by; by = t;             // the activation is where the conv wrote it
+            }
+            continue;
+        }
         if (i == 0) {
             if ((rc = hrn_launch_stem(HRN_F32, x, 2 * plane, x + plane, 1, 2 * plane, means, (const float*)at(packed, L.conv_w[0]),
                                       (const float*)at(packed, L.conv_b[0]), nullptr, bx, B, hsz, hsz, s))) return rc;
@@ -302,7 +322,6 @@ int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* P, const
             p.wpk = at(packed, L.conv_w[i]); p.bias = (const float*)at(packed, L.conv_b[i]);
             if ((rc = hrn_launch_conv3x3(HRN_F32, SN_CI[i], SN_CO[i], p, s))) return rc;
         }
-        const int C = SN_CO[i];
         if (train_bn) {
             if ((rc = hrn_launch_bn_stats(bx, (size_t)B * hsz * hsz, C, P->bn_g[i], P->bn_b[i], 1e-5f, scale, shift,
                                           P->bn_rm[i], P->bn_rv[i], momentum, partial, SN_PARTIAL_BLOCKS, s))) return rc;
@@ -312,8 +331,10 @@ int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* P, const
         if ((rc = hrn_launch_bn_act_pool(bx, scale, shift, by, B, hsz, hsz, C, SN_POOL[i], s))) return rc;
         if (SN_POOL[i]) hsz /= 2;
     }
-    // by: [B][16][16][128] == flat [B][32768] in NHWC order; fc1 weight was permuted to match at pack time
-    if ((rc = hrn_launch_fc1(by, (const float*)at(packed, L.fc1_w), (const float*)at(packed, L.fc1_b), dropout_mask, fc, B, s))) return rc;
+    // by: [B][16][16][128] NHWC -> xr [B][c*256 + hw], the reference's flatten order (dropout folded in); fc1.weight is read in place
+    float* xr = (float*)at(ws, wl.xr);
+    if ((rc = hrn_launch_fc_to_ref(by, dropout_mask, xr, B, s))) return rc;
+    if ((rc = hrn_launch_fc1(xr, P->fc1_w, (const float*)at(packed, L.fc1_b), fc, B, (float*)at(ws, wl.fc_partial), s))) return rc;
     return hrn_launch_fc2(fc, (const float*)at(packed, L.fc2_w), theta, B, s);
 }
 

@@ -48,6 +48,9 @@ int hrn_launch_bn_fold(const float* gamma, const float* beta, const float* rm, c
                        const float* conv_bias, float* scale, float* shift, int C, hipStream_t stream);
 int hrn_launch_bn_act_pool(const float* x, const float* scale, const float* shift, float* out, int N, int H, int W, int C,
                            int pool, hipStream_t stream);
-int hrn_launch_fc1(const float* x, const float* w, const float* b, const unsigned char* mask, float* y, int B, hipStream_t stream);
+// fc1: xr = the input in the reference's flatten order (hrn_launch_fc_to_ref: from the NHWC activation, dropout folded in), w = the raw
+// fc1.weight (1024, 32768), partial = hrn_fc1_partial_bytes() of scratch
+int hrn_launch_fc_to_ref(const float* y, const unsigned char* mask, float* xr, int B, hipStream_t stream);
+size_t hrn_fc1_partial_bytes(void);
+int hrn_launch_fc1(const float* xr, const float* w, const float* b, float* y, int B, float* partial, hipStream_t stream);
 int hrn_launch_fc2(const float* y, const float* w, float* theta, int B, hipStream_t stream);
-int hrn_launch_fc1_pack(const float* w, float* packed, hipStream_t stream);

@@ -190,16 +190,6 @@ __global__ __launch_bounds__(256) void sub_plane_mean_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ fully connected tail
-// xr[b][c*256 + hw] = y[b][hw*128 + c] * (mask ? 2 * mask[b][c*256 + hw] : 1): the fc1 input in the reference's flatten order
-__global__ __launch_bounds__(256) void fc_to_ref_kernel(const float* __restrict__ y, const unsigned char* __restrict__ mask,
-                                                        float* __restrict__ xr, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t b = i / FCK;
-        const int k = (int)(i - b * FCK), c = k >> 8, hw = k & 255;
-        const float v = y[b * FCK + (size_t)hw * 128 + c];
-        xr[i] = mask ? (mask[i] ? 2.f * v : 0.f) : v;
-    }
-}
 // dy[b][hw*128 + c] = dxr[b][c*256 + hw] * (mask ? 2 * mask : 1)
 __global__ __launch_bounds__(256) void fc_from_ref_kernel(const float* __restrict__ dxr, const unsigned char* __restrict__ mask,
                                                           float* __restrict__ dy, size_t total) {
@@ -229,25 +219,37 @@ __global__ __launch_bounds__(256) void fc2_bwd_kernel(const float* __restrict__ 
     dw2[1024 + j] += g1;
     db1[j] += gb;
 }
-// dw1[j][k] += sum_b dz1[b][j] * xr[b][k]      grid (FCK / 256, 1024)
+// dw1[j][k] += sum_b dz1[b][j] * xr[b][k]      grid (FCK / 256, 1024 / 64), B <= 32 per launch.  A thread keeps its column of xr (32
+// samples) in registers and walks 64 neurons: xr is read 16 times in all (it was once per neuron: 4.3 GB of L2 reads for a 268 MB
+// read-modify-write of dw1); dz1[b][j] is the same for the whole workgroup (scalar loads).
+constexpr int FC1_BWD_JT = 64;
 __global__ __launch_bounds__(256) void fc1_bwd_w_kernel(const float* __restrict__ dz1, const float* __restrict__ xr, float* __restrict__ dw1,
                                                         int B) {
-    const int j = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dz1[(size_t)b * 1024 + j] * xr[(size_t)b * FCK + k];
-    dw1[(size_t)j * FCK + k] += s;
+    const int j0 = blockIdx.y * FC1_BWD_JT, k = blockIdx.x * 256 + threadIdx.x;
+    float xv[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) xv[b] = b < B ? xr[(size_t)b * FCK + k] : 0.f;
+    for (int jj = 0; jj < FC1_BWD_JT; ++jj) {
+        const float* dzj = dz1 + j0 + jj;
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) s += (b < B ? dzj[(size_t)b * 1024] : 0.f) * xv[b];
+        float* o = dw1 + (size_t)(j0 + jj) * FCK + k;
+        *o += s;
+    }
 }
-// dxr[b][k] = sum_j dz1[b][j] * w1[j][k]        grid (FCK / 256), B <= 32 per launch
-__global__ __launch_bounds__(256) void fc1_bwd_x_kernel(const float* __restrict__ dz1, const float* __restrict__ w1, float* __restrict__ dxr,
+// dxr[b][k] = sum_j dz1[b][j] * w1[j][k]        grid (FCK / 64) workgroups of ONE wave (512 of them: every CU streams its share of the
+// 134 MB weight read; 128 workgroups of 256 threads left half the chip idle), B <= 32 per launch
+__global__ __launch_bounds__(64) void fc1_bwd_x_kernel(const float* __restrict__ dz1, const float* __restrict__ w1, float* __restrict__ dxr,
                                                         int B) {
     __shared__ float dz[32][64];
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.x * 64 + threadIdx.x;
     float acc[32];
 #pragma unroll
     for (int b = 0; b < 32; ++b) acc[b] = 0.f;
     for (int j0 = 0; j0 < 1024; j0 += 64) {
         __syncthreads();
-        for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        for (int i = threadIdx.x; i < 32 * 64; i += 64) {
             const int b = i >> 6, jj = i & 63;
             dz[b][jj] = b < B ? dz1[(size_t)b * 1024 + j0 + jj] : 0.f;
         }
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void fc1_bwd_x_kernel(const float* __restrict_
 struct SnTrainWs {
     int hin[8], hout[8];
     size_t means, xpre[8], ypost[8], stats[8], y1, partial;
-    size_t ga, gb, xr, dxr, dz1, sums, wt, wtp, zero_bias, dxin, gmeans, scratch;
+    size_t ga, gb, xr, dxr, dz1, sums, wt, wtp, zero_bias, dxin, gmeans, fc_partial, scratch;
     size_t total;
 };
 int sn_cus() { return hrn_device_cus(); }
@@ -295,6 +297,7 @@ SnTrainWs sn_train_ws(int B) {
     w.sums = take(128 * 2 * 8);
     w.wt = take((size_t)128 * 128 * 9 * 4); w.wtp = take((size_t)128 * 128 * 9 * 4); w.zero_bias = take(128 * 4);
     w.dxin = take((size_t)B * 2 * 128 * 128 * 4); w.gmeans = take((size_t)B * 2 * 4);
+    w.fc_partial = take(hrn_fc1_partial_bytes());
     w.scratch = take(hrn_bwd_scratch_bytes(sn_cus()));
     w.total = off;
     return w;
@@ -346,8 +349,11 @@ int hrn_shiftnet_forward_train(const void* packed, const hrn_shiftnet_params* P,
         if ((rc = hrn_launch_bn_act_pool(xp, st + 256, st + 384, yp, B, h, h, C, SN_POOL[i], s))) return rc;
     }
     float* y1 = (float*)at(tws, T.y1);
-    if ((rc = hrn_launch_fc1((const float*)at(tws, T.ypost[7]), (const float*)at(packed, L.fc1_w), (const float*)at(packed, L.fc1_b),
-                             dropout_mask, y1, B, s))) return rc;
+    // fc1's input in the reference's flatten order, dropout folded in: kept in the workspace - the backward's weight gradient reads it
+    HRN_CHECK(P->fc1_w, -2, "hrn_shiftnet_forward_train: params->fc1_w is null (fc1.weight is read in place)");
+    float* xr = (float*)at(tws, T.xr);
+    if ((rc = hrn_launch_fc_to_ref((const float*)at(tws, T.ypost[7]), dropout_mask, xr, B, s))) return rc;
+    if ((rc = hrn_launch_fc1(xr, P->fc1_w, (const float*)at(packed, L.fc1_b), y1, B, (float*)at(tws, T.fc_partial), s))) return rc;
     return hrn_launch_fc2(y1, (const float*)at(packed, L.fc2_w), theta, B, s);
 }
 
@@ -373,10 +379,12 @@ int hrn_shiftnet_backward(const hrn_shiftnet_params* P, const float* x, int B, c
     // ---- tail: theta = fc2(ReLU(fc1(dropout(flatten(y8)))))                                ShiftNet.py:69-74
     hipLaunchKernelGGL(fc2_bwd_kernel, dim3(4), dim3(256), 0, s, d_theta, (const float*)at(tws, T.y1), P->fc2_w, dz1, mut(G->fc2_w), mut(G->fc1_b), B);
     const size_t nflat = (size_t)B * FCK;
-    hipLaunchKernelGGL(fc_to_ref_kernel, dim3(ew_grid(nflat)), dim3(256), 0, s, (const float*)at(tws, T.ypost[7]), dropout_mask, xr, nflat);
-    hipLaunchKernelGGL(fc1_bwd_w_kernel, dim3(FCK / 256, 1024), dim3(256), 0, s, (const float*)dz1, (const float*)xr, mut(G->fc1_w), B);
+    // (xr, the fc1 input in the reference's flatten order with the dropout folded in, was left in the workspace by the forward)
+    for (int b0 = 0; b0 < B; b0 += 32)
+        hipLaunchKernelGGL(fc1_bwd_w_kernel, dim3(FCK / 256, 1024 / FC1_BWD_JT), dim3(256), 0, s, (const float*)dz1 + (size_t)b0 * 1024,
+                           (const float*)xr + (size_t)b0 * FCK, mut(G->fc1_w), B - b0 < 32 ? B - b0 : 32);
     for (int b0 = 0; b0 < B; b0 += 32)      // the kernel keeps 32 samples' partial sums in registers: larger batches go in groups
-        hipLaunchKernelGGL(fc1_bwd_x_kernel, dim3(FCK / 256), dim3(256), 0, s, (const float*)dz1 + (size_t)b0 * 1024, P->fc1_w,
+        hipLaunchKernelGGL(fc1_bwd_x_kernel, dim3(FCK / 64), dim3(64), 0, s, (const float*)dz1 + (size_t)b0 * 1024, P->fc1_w,
                            dxr + (size_t)b0 * FCK, B - b0 < 32 ? B - b0 : 32);
     hipLaunchKernelGGL(fc_from_ref_kernel, dim3(ew_grid(nflat)), dim3(256), 0, s, (const float*)dxr, dropout_mask, cur, nflat);
     HRN_LAUNCH_CHECK();

@@ -132,8 +132,9 @@ size_t hrn_shiftnet_packed_bytes(void);
 int hrn_shiftnet_pack(const hrn_shiftnet_params* params, void* packed, size_t packed_bytes, void* stream);
 size_t hrn_shiftnet_workspace_bytes(int B);
 
-/* x (B,2,128,128) f32 -> theta (B,2) f32.  `params` supplies the live BatchNorm tensors (affine + running stats);
- * its conv/fc pointers are not read here (they live in `packed`).
+/* x (B,2,128,128) f32 -> theta (B,2) f32.  `params` supplies the live BatchNorm tensors (affine + running stats) and
+ * fc1_w, which is read IN PLACE in the reference's layout (its 134 MB are not part of `packed`); the other conv/fc
+ * pointers are not read here (they live in `packed`).
  * train_bn != 0: batch statistics (biased var) and running-stat update with `momentum` (nn.BatchNorm2d train mode);
  * dropout_mask: NULL (eval) or uint8 (B,32768) keep-mask in the reference's flatten order; kept activations x2. */
 int hrn_shiftnet_forward(const void* packed, const hrn_shiftnet_params* params, const float* x, int B,
