@@ -47,7 +47,7 @@ def test_version_and_sizes(lib):
     assert 3 * stack < ws < 3 * stack + B * H * H * (4 + 128) + 4096
     assert lib.hrn_hrnet_workspace_bytes(1, 0, V, H, H) == 0
     conv_bytes = 4 * 9 * (2 * 64 + 3 * 64 * 64 + 64 * 128 + 3 * 128 * 128)
-        assert conv_bytes < lib.hrn_shiftnet_packed_bytes() < conv_bytes + 64 * 1024       # fc1.weight (134 MB) is read in place, not packed
+    assert conv_bytes < lib.hrn_shiftnet_packed_bytes() < conv_bytes + 64 * 1024       # fc1.weight (134 MB) is read in place, not packed
     assert lib.hrn_shiftnet_workspace_bytes(4) > 2 * 4 * 128 * 128 * 64 * 4
 
 
