@@ -165,14 +165,14 @@ def timed_local(step, steps, warmup, device):
     return time.perf_counter() - t0
 
 
-def make_train_step(device, batch, views, patch, overlap=True):
+def make_train_step(device, batch, views, patch, overlap=True, precision="fp32"):
     """The statements of src/train.py:164-191 on the HIP modules (random-init weights, synthetic batch)."""
     from DeepNetworks.HRNet import HRNet
     from DeepNetworks.ShiftNet import ShiftNet
     from hrnet_hip import losses
     from hrnet_hip.optim import FusedAdam
     torch.manual_seed(1234)
-    fusion = HRNet(dict(NETWORK)).to(device).train()
+    fusion = HRNet(dict(NETWORK, precision=precision)).to(device).train()
     regis = ShiftNet().to(device).train()
     with torch.no_grad():
         regis.fc2.weight.normal_(0.0, 1e-3)                       # not the all-zero start: the registration branch does real work
@@ -345,7 +345,8 @@ def main():
         raise SystemExit(f"all_gather saw ranks {seen}, expected {ws}")
 
     if args.mode == "train":
-        step = make_train_step(device, args.batch, args.views, args.patch)
+        tprec = "fp32" if args.precision == "bf16" else args.precision       # (bf16 storage has no training path: fp32 unless bf16x3 is asked for)
+        step = make_train_step(device, args.batch, args.views, args.patch, precision=tprec)
         steps = max(1, min(args.steps, 10))
         warm = max(1, min(args.warmup, 3))
         elapsed = timed(step, steps, warm, device, hdist)
@@ -356,7 +357,7 @@ def main():
                 "value": round(args.batch * ws * steps / elapsed, 2), "unit": "samples/s", "n_gpus": ws, "steps": steps, "warmup": warm,
                 "ms_per_step": round(elapsed / steps * 1e3, 2), "ms_per_step_without_exchange": round(no_x / steps * 1e3, 2),
                 "early_slice_launched_during_backward": bool(step.early) if ws > 1 else None,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": tprec, "data": "synthetic",
                 "ranks_seen": seen, "backend": backend,
                 "config": {"workload": f"train.py:164-191 on the HIP modules: HRNet + ShiftNet + Lanczos + registered cPSNR loss + FusedAdam, "
                                        f"B={args.batch}/GPU, n_views={args.views}, {args.patch}x{args.patch} patches (BASELINE configs[3])",
@@ -576,15 +577,22 @@ def measure_rank0(args, ws, device, net, lrs, alphas, step, sr_holder, binding, 
                         "workload": "BASELINE configs[4]: B=32, n_views=32, 512x512->1536x1536, bf16"}
             extra(extras, "c5_bf16", c5)
 
-        def train():
+        def train(prec):
             binding._ws_cache.clear()
             torch.cuda.empty_cache()
-            tstep = make_train_step(device, 32, 32, 64)
+            tstep = make_train_step(device, 32, 32, 64, precision=prec)
             with torch.enable_grad():
                 t = timed_local(tstep, 3, 2, device) / 3
+                pf = profile_families(binding, device, tstep, 1)
+            top = sorted(pf.items(), key=lambda kv: -kv[1]["ms"])[:6]
+            del tstep
             return {"ms_per_step": round(t * 1e3, 1), "samples_per_s": round(32 / t, 1), "steps": 3,
-                    "workload": "src/train.py:164-191 on the HIP modules, B=32, n_views=32, 64x64 patches, fp32 (python bench.py --mode train)"}
-        extra(extras, "train_step", train)
+                    "top_kernel_families_ms": {k: round(v["ms"], 2) for k, v in top},
+                    "workload": f"src/train.py:164-191 on the HIP modules, B=32, n_views=32, 64x64 patches, HRNet in {prec} "
+                                f"(python bench.py --mode train{'' if prec == 'fp32' else ' --precision ' + prec})"}
+        extra(extras, "train_step", lambda: train("fp32"))
+        if binding.has_bf16x3():
+            extra(extras, "train_step_bf16x3", lambda: train("bf16x3"))
     line.update(extras)
 
     if ws == 1 and not args.no_cpu_baseline:

@@ -157,8 +157,8 @@ class HRNet(nn.Module):
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # .train() mode with grad enabled - the training loop (train.py:160-190), but also src/predict.py, which never calls
             # .eval() and uses no no_grad (predict.py:86-100, :17-49).  Autograd cannot tell us whether a backward pass will follow:
-            #   precision "fp32" (default) / "bf16x3": the fp32 training forward (torch.ops.hrnet_hip.hrnet_forward_train), which keeps its
-            #                               intermediates for the HIP backward (same numbers as the fp32 inference kernels);
+            #   precision "fp32" (default) / "bf16x3": the training forward of that precision (torch.ops.hrnet_hip.hrnet_forward_train), which
+            #                               keeps its intermediates for the HIP backward (same numbers as the inference kernels of that mode);
             #   precision "bf16":           the bf16 inference kernels, as asked for; a backward pass, if one comes, first
             #                               recomputes the forward on the fp32 training kernels (_HRNetLazyTrainFunction).
             # In .eval() mode (validation, train.py:196-215) the inference kernels run and the result carries no autograd graph.
@@ -169,8 +169,11 @@ class HRNet(nn.Module):
             # the dispatcher-registered training op (binding.py): hrn_hrnet_forward_train with hrn_hrnet_backward as its autograd formula
             if names != binding.hrnet_param_names(self._num_layers):
                 raise RuntimeError("HRNet parameters are not in the reference's registration order")
-            sr, _tws = torch.ops.hrnet_hip.hrnet_forward_train(self._packed_f32(), lrs.detach().float().contiguous(), alphas.detach().float().contiguous(),
-                                                               params, self._num_layers, bool(self.fuse.alpha_residual))
+            # precision "bf16x3" trains in split-bf16 too (conv forward, data and weight gradients on the bf16 matrix cores, ~2^-16 per product)
+            dt = self._dtype()
+            packed = self.packed_parameters()[0] if dt == binding.BF16X3 else self._packed_f32()
+            sr, _tws = torch.ops.hrnet_hip.hrnet_forward_train(packed, lrs.detach().float().contiguous(), alphas.detach().float().contiguous(),
+                                                               params, self._num_layers, bool(self.fuse.alpha_residual), dt)
             return sr
         packed, dt = self.packed_parameters()
         return torch.ops.hrnet_hip.hrnet_forward(packed, dt, self._num_layers, bool(self.fuse.alpha_residual), lrs.detach(), alphas.detach())

@@ -77,6 +77,10 @@ SIGNATURES = {
                                            _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_hrnet_backward": (_c.c_int, [_c.c_void_p, _c.POINTER(HrnetParams), _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
                                       _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(HrnetParams), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_hrnet_forward_train_dt": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                              _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "hrn_hrnet_backward_dt": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(HrnetParams), _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
+                                         _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(HrnetParams), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_shiftnet_packed_bytes": (_c.c_size_t, []),
     "hrn_shiftnet_pack": (_c.c_int, [_c.POINTER(ShiftnetParams), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "hrn_shiftnet_workspace_bytes": (_c.c_size_t, [_c.c_int]),
@@ -283,8 +287,9 @@ def hrnet_decoder(packed, dtype, num_layers, fused):
     return sr
 
 
-def hrnet_forward_train(packed_f32, lrs, alphas, num_layers, alpha_residual):
-    """Training forward (fp32): returns (sr, train_ws); train_ws holds every intermediate for hrnet_backward."""
+def hrnet_forward_train(packed_f32, lrs, alphas, num_layers, alpha_residual, dtype=F32):
+    """Training forward: returns (sr, train_ws); train_ws holds every intermediate for hrnet_backward.  dtype F32 (exact-fp32 MFMA) or
+    BF16X3 (split-bf16: `packed_f32` is then the BF16X3 blob and the workspace holds pairs of bf16 planes)."""
     lib = load_library()
     lrs = _dev_f32(lrs, "lrs")
     alphas = _dev_f32(alphas, "alphas")
@@ -295,12 +300,12 @@ def hrnet_forward_train(packed_f32, lrs, alphas, num_layers, alpha_residual):
     tws = torch.empty(nbytes, dtype=torch.uint8, device=lrs.device)
     sr = torch.empty((B, 1, 3 * H, 3 * W), dtype=torch.float32, device=lrs.device)
     with torch.cuda.device(lrs.device):
-        _check(lib.hrn_hrnet_forward_train(_ptr(packed_f32), num_layers, int(bool(alpha_residual)), _ptr(lrs), _ptr(alphas),
-                                           B, V, H, W, _ptr(sr), _ptr(tws), nbytes, _stream()), "hrn_hrnet_forward_train")
+        _check(lib.hrn_hrnet_forward_train_dt(_ptr(packed_f32), int(dtype), num_layers, int(bool(alpha_residual)), _ptr(lrs), _ptr(alphas),
+                                              B, V, H, W, _ptr(sr), _ptr(tws), nbytes, _stream()), "hrn_hrnet_forward_train")
     return sr, tws
 
 
-def hrnet_backward(packed_f32, named_params, named_grads, num_layers, alpha_residual, lrs, alphas, d_sr, tws):
+def hrnet_backward(packed_f32, named_params, named_grads, num_layers, alpha_residual, lrs, alphas, d_sr, tws, dtype=F32):
     """Accumulates dLoss/dparam into named_grads (same keys / shapes as named_params, f32, zero them for plain gradients)."""
     lib = load_library()
     lrs = _dev_f32(lrs, "lrs")
@@ -315,8 +320,8 @@ def hrnet_backward(packed_f32, named_params, named_grads, num_layers, alpha_resi
         if t.shape != g.shape or g.data_ptr() == t.data_ptr():
             raise ValueError("gradient buffers must match the parameters' shapes and not alias them")
     with torch.cuda.device(lrs.device):
-        _check(lib.hrn_hrnet_backward(_ptr(packed_f32), ctypes.byref(P), int(bool(alpha_residual)), _ptr(lrs), _ptr(alphas),
-                                      B, V, H, W, _ptr(d_sr), ctypes.byref(G), _ptr(tws), tws.numel(), _stream()),
+        _check(lib.hrn_hrnet_backward_dt(_ptr(packed_f32), int(dtype), ctypes.byref(P), int(bool(alpha_residual)), _ptr(lrs), _ptr(alphas),
+                                         B, V, H, W, _ptr(d_sr), ctypes.byref(G), _ptr(tws), tws.numel(), _stream()),
                "hrn_hrnet_backward")
 
 
@@ -650,14 +655,15 @@ SHIFTNET_BUFFER_NAMES = [f"layer{i}.1.{k}" for i in range(1, 9) for k in ("runni
 
 @torch.library.custom_op("hrnet_hip::hrnet_forward_train", mutates_args=(), device_types="cuda")
 def _op_hrnet_forward_train(packed: torch.Tensor, lrs: torch.Tensor, alphas: torch.Tensor, params: Sequence[torch.Tensor],
-                            num_layers: int, alpha_residual: bool) -> Tuple[torch.Tensor, torch.Tensor]:
-    """`srs = fusion_model(lrs, alphas)` in training (train.py:174): fp32 forward that keeps every intermediate in `tws`.  `packed` is the
-    F32 blob of `params` (the raw parameters travel along for the backward pass and as the differentiable inputs)."""
-    return hrnet_forward_train(packed, lrs, alphas, num_layers, alpha_residual)
+                            num_layers: int, alpha_residual: bool, dtype: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`srs = fusion_model(lrs, alphas)` in training (train.py:174): the forward that keeps every intermediate in `tws`, in fp32 (dtype 0)
+    or split-bf16 (dtype 2).  `packed` is the blob of `params` for that dtype (the raw parameters travel along for the backward pass and
+    as the differentiable inputs)."""
+    return hrnet_forward_train(packed, lrs, alphas, num_layers, alpha_residual, dtype)
 
 
 @_op_hrnet_forward_train.register_fake
-def _(packed, lrs, alphas, params, num_layers, alpha_residual):
+def _(packed, lrs, alphas, params, num_layers, alpha_residual, dtype):
     b, v, h, w = lrs.shape
     nbytes = load_library().hrn_hrnet_train_workspace_bytes(num_layers, b, v, h, w)
     return lrs.new_empty((b, 1, 3 * h, 3 * w), dtype=torch.float32), lrs.new_empty((nbytes,), dtype=torch.uint8)
@@ -665,23 +671,23 @@ def _(packed, lrs, alphas, params, num_layers, alpha_residual):
 
 @torch.library.custom_op("hrnet_hip::hrnet_backward", mutates_args=("tws",), device_types="cuda")     # (tws also holds the backward's scratch buffers)
 def _op_hrnet_backward(packed: torch.Tensor, params: Sequence[torch.Tensor], lrs: torch.Tensor, alphas: torch.Tensor, d_sr: torch.Tensor,
-                       tws: torch.Tensor, num_layers: int, alpha_residual: bool) -> List[torch.Tensor]:
+                       tws: torch.Tensor, num_layers: int, alpha_residual: bool, dtype: int) -> List[torch.Tensor]:
     """d_sr -> the gradient of every parameter (train.py:190 through HRNet), in `hrnet_param_names` order."""
     names = hrnet_param_names(num_layers)
     named = dict(zip(names, params))
     grads = {k: torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for k, p in named.items()}
-    hrnet_backward(packed, named, grads, num_layers, alpha_residual, lrs, alphas, d_sr.contiguous(), tws)
+    hrnet_backward(packed, named, grads, num_layers, alpha_residual, lrs, alphas, d_sr.contiguous(), tws, dtype)
     return [grads[k] for k in names]
 
 
 @_op_hrnet_backward.register_fake
-def _(packed, params, lrs, alphas, d_sr, tws, num_layers, alpha_residual):
+def _(packed, params, lrs, alphas, d_sr, tws, num_layers, alpha_residual, dtype):
     return [p.new_empty(p.shape, dtype=torch.float32) for p in params]
 
 
 def _hrnet_train_setup(ctx, inputs, output):
-    packed, lrs, alphas, params, num_layers, alpha_residual = inputs
-    ctx.num_layers, ctx.alpha_residual, ctx.n = num_layers, alpha_residual, len(params)
+    packed, lrs, alphas, params, num_layers, alpha_residual, dtype = inputs
+    ctx.num_layers, ctx.alpha_residual, ctx.n, ctx.dtype = num_layers, alpha_residual, len(params), dtype
     ctx.save_for_backward(packed, lrs, alphas, output[1], *params)
 
 
@@ -689,8 +695,8 @@ def _hrnet_train_backward(ctx, d_sr, _d_tws):
     packed, lrs, alphas, tws, *params = ctx.saved_tensors
     # (tws.data: the backward's scratch buffers live in tws too, so the op declares it mutated; through an alias with its own version
     # counter the saved tensor stays valid for a second backward pass - backward(retain_graph=True), the kept intermediates are only read)
-    grads = torch.ops.hrnet_hip.hrnet_backward(packed, params, lrs, alphas, d_sr, tws.data, ctx.num_layers, ctx.alpha_residual)
-    return None, None, None, [g.to(p.dtype) for g, p in zip(grads, params)], None, None
+    grads = torch.ops.hrnet_hip.hrnet_backward(packed, params, lrs, alphas, d_sr, tws.data, ctx.num_layers, ctx.alpha_residual, ctx.dtype)
+    return None, None, None, [g.to(p.dtype) for g, p in zip(grads, params)], None, None, None
 
 
 _op_hrnet_forward_train.register_autograd(_hrnet_train_backward, setup_context=_hrnet_train_setup)

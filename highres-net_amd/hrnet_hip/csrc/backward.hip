@@ -44,22 +44,23 @@ __global__ __launch_bounds__(256) void scalar_finish_kernel(const double* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (bias grads)
-template <int C>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, size_t rows, double* __restrict__ partial) {
+template <int C, bool X3>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ g, size_t rows, double* __restrict__ partial) {
     // thread -> 4 channels c4*4.., row phase tid / (C/4); 16-byte loads, four rows in flight per thread; fixed order
     constexpr int C4 = C / 4, RP = 256 / C4;
     const int c4 = threadIdx.x % C4, rp = threadIdx.x / C4;
+    const size_t lo = rows * C * 2;                             // (X3: the lo plane of the [rows][C] tensor)
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const size_t stride = (size_t)gridDim.x * RP;
     size_t r = (size_t)blockIdx.x * RP + rp;
     for (; r + 3 * stride < rows; r += 4 * stride) {
-        const f32x4 v0 = *(const f32x4*)(g + r * C + c4 * 4), v1 = *(const f32x4*)(g + (r + stride) * C + c4 * 4);
-        const f32x4 v2 = *(const f32x4*)(g + (r + 2 * stride) * C + c4 * 4), v3 = *(const f32x4*)(g + (r + 3 * stride) * C + c4 * 4);
+        const f32x4 v0 = act_ld4<X3>(g, lo, r * C4 + c4), v1 = act_ld4<X3>(g, lo, (r + stride) * C4 + c4);
+        const f32x4 v2 = act_ld4<X3>(g, lo, (r + 2 * stride) * C4 + c4), v3 = act_ld4<X3>(g, lo, (r + 3 * stride) * C4 + c4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] += ((double)v0[j] + (double)v1[j]) + ((double)v2[j] + (double)v3[j]);
     }
     for (; r < rows; r += stride) {
-        const f32x4 v = *(const f32x4*)(g + r * C + c4 * 4);
+        const f32x4 v = act_ld4<X3>(g, lo, r * C4 + c4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] += (double)v[j];
     }
@@ -81,22 +82,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 // order of colsum_kernel (fixed: bit-reproducible); g may alias dy.  With a positive slope the sign of x is the sign of the stored
 // post-activation y and x = y / slope where it is negative; otherwise (decided here, on the device: no host round trip) the
 // pre-activation itself is read from xpre, which the caller has recomputed under the same condition.
-template <int C>
-__global__ __launch_bounds__(256) void prelu_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             const float* __restrict__ xpre, const float* __restrict__ slope,
-                                                             float* __restrict__ g, size_t rows, double* __restrict__ colpart,
+template <int C, bool X3>
+__global__ __launch_bounds__(256) void prelu_bwd_bias_kernel(const void* __restrict__ dy, const void* __restrict__ y,
+                                                             const void* __restrict__ xpre, const float* __restrict__ slope,
+                                                             void* __restrict__ g, size_t rows, double* __restrict__ colpart,
                                                              double* __restrict__ slopepart) {
     constexpr int C4 = C / 4, RP = 256 / C4;
     const int c4 = threadIdx.x % C4, rp = threadIdx.x / C4;
+    const size_t lo = rows * C * 2;                             // (X3: the lo plane of each [rows][C] tensor)
     const float a = slope[0];
     const bool from_y = a > 0.f;
-    const float* __restrict__ src = from_y ? y : xpre;
+    const void* __restrict__ src = from_y ? y : xpre;
     const float inv_a = from_y ? 1.f / a : 1.f;
     double acc[4] = {0.0, 0.0, 0.0, 0.0}, sacc = 0.0;
     const size_t stride = (size_t)gridDim.x * RP;
     auto one = [&](size_t r) __attribute__((always_inline)) {
-        const size_t o4 = r * C + c4 * 4;
-        const f32x4 d = BWD_LD((const f32x4*)(dy + o4)), v = BWD_LD((const f32x4*)(src + o4));
+        const size_t o4 = r * C4 + c4;
+        const f32x4 d = act_ld4<X3>(dy, lo, o4), v = act_ld4<X3>(src, lo, o4);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(256) void prelu_bwd_bias_kernel(const float* __rest
             acc[j] += (double)o[j];
             if (!pos) sacc += (double)d[j] * ((double)v[j] * (double)inv_a);      // signed terms that largely cancel: fp64
         }
-        *(f32x4*)(g + o4) = o;
+        if constexpr (X3) act_st4<true>(g, lo, o4, o);
+        else *((f32x4*)g + o4) = o;
     };
     size_t r = (size_t)blockIdx.x * RP + rp;
     for (; r + stride < rows; r += 2 * stride) { one(r); one(r + stride); }
@@ -340,9 +343,10 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ partial, int nblk,
 
 // ------------------------------------------------------------------------------------------------ stem weight gradient
 // dW[co][c2][tap] += sum g[m][p][co] * in_c2[m][p + tap], in_0 = view m, in_1 = reference frame of sample m / rep1
+template <bool X3>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ in0, size_t stride0, const float* __restrict__ in1,
                                                          int rep1, size_t stride1, const float* __restrict__ sub,
-                                                         const float* __restrict__ g, int M, int H, int W, float* __restrict__ partial) {
+                                                         const void* __restrict__ g, int M, int H, int W, float* __restrict__ partial) {
     __shared__ float tile[2][WG_HH][WG_HW];
     const int tid = threadIdx.x, co = tid & 63, q = tid >> 6;
     const int tiles_x = (W + WG_TW - 1) / WG_TW, tiles_y = (H + WG_TH - 1) / WG_TH;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             tile[c][py][px] = v;
         }
         __syncthreads();
-        const float* gb = g + (size_t)m * hw * 64 + co;
+        const size_t gb = (size_t)m * hw * 64 + co, glo = (size_t)M * hw * 64 * 2;
         // eight of the thread's 64 pixels at a time: their loads of g are in flight together (the loop is latency-bound otherwise);
         // pixels outside the image contribute zero
         for (int p8 = 0; p8 < WG_TH * WG_TW / 4; p8 += 8) {
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int pix = q + 4 * (p8 + u), gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-                gv[u] = (gy < H && gx < W) ? gb[((size_t)gy * W + gx) * 64] : 0.f;
+                gv[u] = (gy < H && gx < W) ? act_ld1<X3>(g, glo, gb + ((size_t)gy * W + gx) * 64) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -413,58 +417,65 @@ __global__ __launch_bounds__(256) void stem_wgrad_finish_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise helpers
-__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n4) {
+template <bool X3>
+__global__ __launch_bounds__(256) void add_kernel(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ o, size_t n4) {
+    const size_t lo = n4 * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
-        BWD_ST(((f32x4*)o) + i, BWD_LD(((const f32x4*)a) + i) + BWD_LD(((const f32x4*)b) + i));
+        act_st4<X3>(o, lo, i, act_ld4<X3>(a, lo, i) + act_ld4<X3>(b, lo, i));
 }
 
 // fusion level, forward: s'[b][i] = s[b][i] + alpha[b][partner(i)] * f[b][i]   (or s' = f without the alpha residual)
-__global__ __launch_bounds__(256) void fuse_update_kernel(const float* __restrict__ stack, int n_in, const float* __restrict__ f,
+template <bool X3>
+__global__ __launch_bounds__(256) void fuse_update_kernel(const void* __restrict__ stack, int n_in, const void* __restrict__ f,
                                                           const float* __restrict__ alphas, int alpha_vs, int pair_last, int half,
-                                                          int alpha_residual, float* __restrict__ out, size_t img4, int B) {
+                                                          int alpha_residual, void* __restrict__ out, size_t img4, int B) {
     const size_t total = (size_t)B * half * img4;
+    const size_t lo_s = (size_t)B * n_in * img4 * 8, lo_f = total * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t img = i / img4, e = i - img * img4;
         const int b = (int)(img / half), v = (int)(img - (size_t)b * half);
-        const f32x4 fv = ((const f32x4*)f)[i];
+        const f32x4 fv = act_ld4<X3>(f, lo_f, i);
         if (alpha_residual) {
             const float al = alphas[(size_t)b * alpha_vs + (pair_last - v)];
-            ((f32x4*)out)[i] = ((const f32x4*)stack)[((size_t)b * n_in + v) * img4 + e] + al * fv;
+            act_st4<X3>(out, lo_f, i, act_ld4<X3>(stack, lo_s, ((size_t)b * n_in + v) * img4 + e) + al * fv);
         } else {
-            ((f32x4*)out)[i] = fv;
+            act_st4<X3>(out, lo_f, i, fv);
         }
     }
 }
 // fusion level, backward: df[b][i] = alpha_partner * ds'[b][i]  (or ds')
-__global__ __launch_bounds__(256) void fuse_df_kernel(const float* __restrict__ dsn, const float* __restrict__ alphas, int alpha_vs,
-                                                      int pair_last, int half, int alpha_residual, float* __restrict__ df, size_t img4,
+template <bool X3>
+__global__ __launch_bounds__(256) void fuse_df_kernel(const void* __restrict__ dsn, const float* __restrict__ alphas, int alpha_vs,
+                                                      int pair_last, int half, int alpha_residual, void* __restrict__ df, size_t img4,
                                                       int B) {
-    const size_t total = (size_t)B * half * img4;
+    const size_t total = (size_t)B * half * img4, lo = total * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t img = i / img4;
         const int b = (int)(img / half), v = (int)(img - (size_t)b * half);
         const float al = alpha_residual ? alphas[(size_t)b * alpha_vs + (pair_last - v)] : 1.f;
-        ((f32x4*)df)[i] = al * ((const f32x4*)dsn)[i];
+        act_st4<X3>(df, lo, i, al * act_ld4<X3>(dsn, lo, i));
     }
 }
 // fusion level, backward: gradient of the level's input views from ds' (alice pass-through, alpha residual only) and
 // dz [B*half][HW][128] (channels 0..63 -> view i, 64..127 -> view pair_last - i); views that took no part get zero
-__global__ __launch_bounds__(256) void fuse_scatter_kernel(const float* __restrict__ dsn, const float* __restrict__ dz, int n_in, int half,
-                                                           int pair_last, int alpha_residual, float* __restrict__ ds, size_t hw, int B) {
+template <bool X3>
+__global__ __launch_bounds__(256) void fuse_scatter_kernel(const void* __restrict__ dsn, const void* __restrict__ dz, int n_in, int half,
+                                                           int pair_last, int alpha_residual, void* __restrict__ ds, size_t hw, int B) {
     const size_t img4 = hw * 16;                                // float4 per 64-channel image
     const size_t total = (size_t)B * n_in * img4;
+    const size_t lo_n = (size_t)B * half * img4 * 8, lo_z = (size_t)B * half * hw * 32 * 8, lo_s = total * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t img = i / img4, e = i - img * img4;
         const int b = (int)(img / n_in), v = (int)(img - (size_t)b * n_in);
         const size_t pix = e >> 4, part = e & 15;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         if (v < half) {
-            if (alpha_residual) o = ((const f32x4*)dsn)[((size_t)b * half + v) * img4 + e];
-            o += ((const f32x4*)dz)[(((size_t)b * half + v) * hw + pix) * 32 + part];
+            if (alpha_residual) o = act_ld4<X3>(dsn, lo_n, ((size_t)b * half + v) * img4 + e);
+            o += act_ld4<X3>(dz, lo_z, (((size_t)b * half + v) * hw + pix) * 32 + part);
         } else if (v <= pair_last && pair_last - v < half) {
-            o = ((const f32x4*)dz)[(((size_t)b * half + (pair_last - v)) * hw + pix) * 32 + 16 + part];
+            o = act_ld4<X3>(dz, lo_z, (((size_t)b * half + (pair_last - v)) * hw + pix) * 32 + 16 + part);
         }
-        ((f32x4*)ds)[i] = o;
+        act_st4<X3>(ds, lo_s, i, o);
     }
 }
 
@@ -476,30 +487,36 @@ int red_grid(size_t n4) {
 }  // namespace
 
 size_t hrn_bwd_scratch_bytes(int num_cus) {
-    // wgrad partial slabs (one (cout chunk, cin chunk) pair at a time) + reduction partials
-    return (size_t)num_cus * 9 * 4096 * 4 + (size_t)RED_BLOCKS * (128 + 1) * 8 + 4096;
+    // wgrad partial slabs (one (cout chunk, cin chunk) pair at a time; the bf16x3 kernel runs two workgroups per CU) + reduction partials
+    return (size_t)2 * num_cus * 9 * 4096 * 4 + (size_t)RED_BLOCKS * (128 + 1) * 8 + 4096;
 }
 
 int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* xpre, const float* slope, float* g, size_t rows, int C,
-                              float* dslope, float* db, void* scratch, hipStream_t s) {
+                              float* dslope, float* db, void* scratch, hipStream_t s, int dt) {
     HRN_CHECK(C == 64 || C == 128, -2, "prelu_bwd_bias: C must be 64 or 128 (got %d)", C);
     double* colpart = (double*)scratch;
     const int blocks = RED_BLOCKS;
     double* slopepart = colpart + (size_t)blocks * 128;
-    if (C == 64) hipLaunchKernelGGL(prelu_bwd_bias_kernel<64>, dim3(blocks), dim3(256), 0, s, dy, y, xpre, slope, g, rows, colpart, slopepart);
-    else hipLaunchKernelGGL(prelu_bwd_bias_kernel<128>, dim3(blocks), dim3(256), 0, s, dy, y, xpre, slope, g, rows, colpart, slopepart);
+    const bool x3 = dt == HRN_BF16X3;
+#define HRN_PB(C_, X_) hipLaunchKernelGGL((prelu_bwd_bias_kernel<C_, X_>), dim3(blocks), dim3(256), 0, s, (const void*)dy, (const void*)y, (const void*)xpre, slope, (void*)g, rows, colpart, slopepart)
+    if (C == 64) { if (x3) HRN_PB(64, true); else HRN_PB(64, false); }
+    else { if (x3) HRN_PB(128, true); else HRN_PB(128, false); }
+#undef HRN_PB
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(256), 0, s, colpart, blocks, C, db);
     hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, slopepart, blocks, dslope);
     HRN_LAUNCH_CHECK();
     return 0;
 }
 
-int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scratch, hipStream_t s) {
+int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scratch, hipStream_t s, int dt) {
     HRN_CHECK(C == 64 || C == 128, -2, "colsum: C must be 64 or 128 (got %d)", C);
     double* partial = (double*)scratch;
     const int blocks = RED_BLOCKS;
-    if (C == 64) hipLaunchKernelGGL(colsum_kernel<64>, dim3(blocks), dim3(256), 0, s, g, rows, partial);
-    else hipLaunchKernelGGL(colsum_kernel<128>, dim3(blocks), dim3(256), 0, s, g, rows, partial);
+    const bool x3 = dt == HRN_BF16X3;
+#define HRN_CS(C_, X_) hipLaunchKernelGGL((colsum_kernel<C_, X_>), dim3(blocks), dim3(256), 0, s, (const void*)g, rows, partial)
+    if (C == 64) { if (x3) HRN_CS(64, true); else HRN_CS(64, false); }
+    else { if (x3) HRN_CS(128, true); else HRN_CS(128, false); }
+#undef HRN_CS
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(256), 0, s, partial, blocks, C, db);
     HRN_LAUNCH_CHECK();
     return 0;
@@ -508,6 +525,12 @@ int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scrat
 int hrn_launch_dgrad_weights(const float* w, float* wt, int cin, int cout, hipStream_t s) {
     const int total = cin * cout * 9;
     hipLaunchKernelGGL(dgrad_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, wt, cin, cout);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hrn_launch_wgrad_finish(const float* partial, int nblk, float* dw, int cin, int co_chunk, int ci_chunk, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(9 * 4096 / 64), dim3(256), 0, s, partial, nblk, dw, cin, co_chunk, ci_chunk);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -535,62 +558,74 @@ int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int p
 }
 
 int hrn_launch_stem_wgrad(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* g, int M, int H,
-                          int W, float* dw, void* scratch, int num_cus, hipStream_t s) {
-    return hrn_launch_stem_wgrad_sub(in0, stride0, in1, rep1, stride1, nullptr, g, M, H, W, dw, scratch, num_cus, s);
+                          int W, float* dw, void* scratch, int num_cus, hipStream_t s, int dt) {
+    return hrn_launch_stem_wgrad_sub(in0, stride0, in1, rep1, stride1, nullptr, g, M, H, W, dw, scratch, num_cus, s, dt);
 }
 
 int hrn_launch_stem_wgrad_sub(const float* in0, size_t stride0, const float* in1, int rep1, size_t stride1, const float* sub,
-                              const float* g, int M, int H, int W, float* dw, void* scratch, int num_cus, hipStream_t s) {
+                              const float* g, int M, int H, int W, float* dw, void* scratch, int num_cus, hipStream_t s, int dt) {
     const long tiles = (long)((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * M;
     int grid = 4 * num_cus;                 // four workgroups per CU: the kernel waits on memory, not on arithmetic
     if (tiles < grid) grid = (int)tiles;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, sub, g, M, H, W, (float*)scratch);
+    if (dt == HRN_BF16X3) hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, sub, (const void*)g, M, H, W, (float*)scratch);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, sub, (const void*)g, M, H, W, (float*)scratch);
     hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3(64 * 18 / 16), dim3(256), 0, s, (const float*)scratch, grid * 4, dw);
     HRN_LAUNCH_CHECK();
     return 0;
 }
 
-int hrn_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t s) {
+int hrn_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t s, int dt) {
     HRN_CHECK(n % 4 == 0, -2, "add: element count %zu not a multiple of 4", n);
-    hipLaunchKernelGGL(add_kernel, dim3(red_grid(n / 4)), dim3(256), 0, s, a, b, o, n / 4);
+    if (dt == HRN_BF16X3) hipLaunchKernelGGL(add_kernel<true>, dim3(red_grid(n / 4)), dim3(256), 0, s, (const void*)a, (const void*)b, (void*)o, n / 4);
+    else hipLaunchKernelGGL(add_kernel<false>, dim3(red_grid(n / 4)), dim3(256), 0, s, (const void*)a, (const void*)b, (void*)o, n / 4);
     HRN_LAUNCH_CHECK();
     return 0;
 }
 
 int hrn_launch_fuse_update(const float* stack, int n_in, const float* f, const float* alphas, int alpha_vs, int pair_last, int half,
-                           int alpha_residual, float* out, size_t hw, int B, hipStream_t s) {
+                           int alpha_residual, float* out, size_t hw, int B, hipStream_t s, int dt) {
     const size_t img4 = hw * 16;
-    hipLaunchKernelGGL(fuse_update_kernel, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, stack, n_in, f, alphas, alpha_vs,
-                       pair_last, half, alpha_residual, out, img4, B);
+    if (dt == HRN_BF16X3) hipLaunchKernelGGL(fuse_update_kernel<true>, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, (const void*)stack, n_in, (const void*)f, alphas, alpha_vs,
+                                             pair_last, half, alpha_residual, (void*)out, img4, B);
+    else hipLaunchKernelGGL(fuse_update_kernel<false>, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, (const void*)stack, n_in, (const void*)f, alphas, alpha_vs,
+                            pair_last, half, alpha_residual, (void*)out, img4, B);
     HRN_LAUNCH_CHECK();
     return 0;
 }
 
 int hrn_launch_fuse_df(const float* dsn, const float* alphas, int alpha_vs, int pair_last, int half, int alpha_residual, float* df,
-                       size_t hw, int B, hipStream_t s) {
+                       size_t hw, int B, hipStream_t s, int dt) {
     const size_t img4 = hw * 16;
-    hipLaunchKernelGGL(fuse_df_kernel, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, dsn, alphas, alpha_vs, pair_last, half,
-                       alpha_residual, df, img4, B);
+    if (dt == HRN_BF16X3) hipLaunchKernelGGL(fuse_df_kernel<true>, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, (const void*)dsn, alphas, alpha_vs, pair_last, half,
+                                             alpha_residual, (void*)df, img4, B);
+    else hipLaunchKernelGGL(fuse_df_kernel<false>, dim3(red_grid((size_t)B * half * img4)), dim3(256), 0, s, (const void*)dsn, alphas, alpha_vs, pair_last, half,
+                            alpha_residual, (void*)df, img4, B);
     HRN_LAUNCH_CHECK();
     return 0;
 }
 
 int hrn_launch_fuse_scatter(const float* dsn, const float* dz, int n_in, int half, int pair_last, int alpha_residual, float* ds,
-                            size_t hw, int B, hipStream_t s) {
-    hipLaunchKernelGGL(fuse_scatter_kernel, dim3(red_grid((size_t)B * n_in * hw * 16)), dim3(256), 0, s, dsn, dz, n_in, half, pair_last,
-                       alpha_residual, ds, hw, B);
+                            size_t hw, int B, hipStream_t s, int dt) {
+    if (dt == HRN_BF16X3) hipLaunchKernelGGL(fuse_scatter_kernel<true>, dim3(red_grid((size_t)B * n_in * hw * 16)), dim3(256), 0, s, (const void*)dsn, (const void*)dz, n_in, half, pair_last,
+                                             alpha_residual, (void*)ds, hw, B);
+    else hipLaunchKernelGGL(fuse_scatter_kernel<false>, dim3(red_grid((size_t)B * n_in * hw * 16)), dim3(256), 0, s, (const void*)dsn, (const void*)dz, n_in, half, pair_last,
+                            alpha_residual, (void*)ds, hw, B);
     HRN_LAUNCH_CHECK();
     return 0;
 }
 
 int hrn_conv_dgrad(int cin, int cout, const float* w, const float* g, float* dx, const float* res, int M, int H, int W, float* wt,
-                   void* wtp, const float* zero_bias, hipStream_t s) {
+                   void* wtp, const float* zero_bias, hipStream_t s, int dt) {
     int rc;
     if ((rc = hrn_launch_dgrad_weights(w, wt, cin, cout, s))) return rc;
-    if ((rc = hrn_launch_conv_pack(HRN_F32, cout, cin, wt, wtp, s))) return rc;           // a cout -> cin convolution
+    if ((rc = hrn_launch_conv_pack(dt, cout, cin, wt, wtp, s))) return rc;               // a cout -> cin convolution
     ConvParams p = ConvParams();
     p.M = M; p.H = H; p.W = W;
     p.in = g; p.out = dx; p.wpk = wtp; p.bias = zero_bias; p.slope = nullptr;
     if (res) { p.res = res; p.res_mode = 1; }
-    return hrn_launch_conv3x3(HRN_F32, cout, cin, p, s);
+    if (dt == HRN_BF16X3) {               // every tensor a pair of bf16 planes, the lo plane directly behind the hi plane
+        const size_t px = (size_t)M * H * W;
+        p.in_lo = px * cout * 2; p.out_lo = px * cin * 2; p.res_lo = px * cin * 2;
+    }
+    return hrn_launch_conv3x3(dt, cout, cin, p, s);
 }

@@ -52,6 +52,11 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// two floats -> their (hi, lo) bf16 split, packed like pack2_bf16: hi = bf16(v), lo = bf16(v - hi)
+__device__ __forceinline__ void split2_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pack2_bf16(a, b);
+    lo = pack2_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
 
 // 4 x 4 transpose of 16-byte items across each quad of lanes (4k .. 4k+3): x[j] of lane i <- x[i] of lane j (b0 / b1 = bit 0 /
 // bit 1 of the lane id).  Two butterfly stages of v_mov_dpp quad_perm + v_cndmask per dword, 64 VALU per call.  The conv
@@ -113,11 +118,42 @@ template <> __device__ __forceinline__ void store4<HRN_BF16>(void* p, size_t i, 
     *(uint2*)((unsigned short*)p + i) = u;
 }
 
+// ------------------------------------------------------------------ activation tensors of the training path
+// f32, or (X3 = the bf16x3 mode) a PAIR of bf16 planes: hi at p, lo `lo` bytes further on; a tensor of n elements has lo = 2 n (the lo
+// plane directly behind the hi plane), which is how every kernel derives it from the tensor's shape.  Unit: 4 consecutive elements.
+template <bool X3> __device__ __forceinline__ f32x4 act_ld4(const void* p, size_t lo, size_t i4) {
+    if constexpr (X3) {
+        const u32x2 h = __builtin_nontemporal_load((const u32x2*)p + i4);
+        const u32x2 l = __builtin_nontemporal_load((const u32x2*)((const unsigned char*)p + lo) + i4);
+        f32x4 r;
+        r[0] = __uint_as_float(h[0] << 16) + __uint_as_float(l[0] << 16);
+        r[1] = __uint_as_float(h[0] & 0xffff0000u) + __uint_as_float(l[0] & 0xffff0000u);
+        r[2] = __uint_as_float(h[1] << 16) + __uint_as_float(l[1] << 16);
+        r[3] = __uint_as_float(h[1] & 0xffff0000u) + __uint_as_float(l[1] & 0xffff0000u);
+        return r;
+    } else {
+        return __builtin_nontemporal_load((const f32x4*)p + i4);
+    }
+}
+template <bool X3> __device__ __forceinline__ void act_st4(void* p, size_t lo, size_t i4, f32x4 v) {
+    if constexpr (X3) {
+        unsigned h0, l0, h1, l1;
+        split2_bf16(v[0], v[1], h0, l0);
+        split2_bf16(v[2], v[3], h1, l1);
+        const u32x2 h = {h0, h1}, l = {l0, l1};
+        __builtin_nontemporal_store(h, (u32x2*)p + i4);
+        __builtin_nontemporal_store(l, (u32x2*)((unsigned char*)p + lo) + i4);
+    } else {
+        __builtin_nontemporal_store(v, (f32x4*)p + i4);
+    }
+}
+// one element
+template <bool X3> __device__ __forceinline__ float act_ld1(const void* p, size_t lo, size_t i) {
+    if constexpr (X3) return bf16_bits_to_f32(((const unsigned short*)p)[i]) + bf16_bits_to_f32(((const unsigned short*)((const unsigned char*)p + lo))[i]);
+    else return ((const float*)p)[i];
+}
+
 static inline size_t hrn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // bytes per element of an activation / weight tensor (bf16x3: both planes together)
 static inline int hrn_esize(int dt) { return dt == HRN_BF16 ? 2 : 4; }
-// two floats -> their (hi, lo) bf16 split, packed like pack2_bf16: hi = bf16(v), lo = bf16(v - hi)
-__device__ __forceinline__ void split2_bf16(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = pack2_bf16(a, b);
-    lo = pack2_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
-}
+

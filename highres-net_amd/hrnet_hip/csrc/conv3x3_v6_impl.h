@@ -106,6 +106,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
     constexpr int BAL = COUT == 128 ? V6_BAL : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_lds = (float*)(smem + GEO::OFF_BIAS);
+    if constexpr (X3) {     // (ConvParams::only_if_nonpos: the backward's recomputation of a pre-activation, needed only behind a PReLU slope <= 0)
+        if (p.only_if_nonpos && p.only_if_nonpos[0] > 0.f) return;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                 resA = (const unsigned char*)p.stack + ((size_t)bb * p.pair_vs + i) * hw * 128;
                 resB = (const unsigned char*)p.stack + ((size_t)bb * p.pair_vs + (p.pair_last - i)) * hw * 128;
             }
-            if (RESM == 1) resA = resB = (const unsigned char*)p.res + (size_t)cur_m * hw * 128;     // plain residual tensor, COUT = 64
+            if (RESM == 1) resA = resB = (const unsigned char*)p.res + (size_t)cur_m * hw * ROW;     // plain residual tensor [M][H][W][COUT]
             outp = (unsigned char*)p.out + oimg * hw * ROW;
         }
         // the residual of round r (= pixel block r of the wave), piece j: lane (q, c15) fetches its own share of pixel 4q + j, i.e. of
@@ -292,8 +295,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
             const int gy = y0 + 2 * w + (r >> 1), gyc = gy < H ? gy : H - 1;
             const int gx = x0 + 16 * (r & 1) + 4 * qr + j, gxc = gx < W ? gx : W - 1;
             const unsigned char* view = (RESM == 2 && c15r >= 8) ? resB : resA;
-            if (V6_ABL & 64) return resA + ((unsigned)(((gyc * W + gxc) & 511) * 128) + (RESM == 2 ? (unsigned)((c15r & 7) * 16) : (unsigned)(c15r * LB)));
-            return view + ((unsigned)((gyc * W + gxc) * 128) + (RESM == 2 ? (unsigned)((c15r & 7) * 16) : (unsigned)(c15r * LB)));
+            constexpr int RPITCH = RESM == 1 ? ROW : 128;       // bytes per pixel of the residual: a 64-channel view of the stack, or the plain tensor
+            if (V6_ABL & 64) return resA + ((unsigned)(((gyc * W + gxc) & 511) * RPITCH) + (RESM == 2 ? (unsigned)((c15r & 7) * 16) : (unsigned)(c15r * LB)));
+            return view + ((unsigned)((gyc * W + gxc) * RPITCH) + (RESM == 2 ? (unsigned)((c15r & 7) * 16) : (unsigned)(c15r * LB)));
         };
         constexpr bool FIFO = RES && LB == 16 && !X3;       // (there is no 8-byte LDS-DMA: the 64-cout layer fetches round 0 like the others)
         // round 0 goes into the wave's 4 KB of LDS by DMA while the tile's last stage computes (no registers to hold it beside the

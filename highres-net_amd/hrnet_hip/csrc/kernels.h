@@ -10,8 +10,9 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
                     const float* sub, const float* w, const float* bias, const float* slope, void* out,
                     int M, int H, int W, hipStream_t stream, size_t out_lo = 0);       // out_lo: HRN_BF16X3's lo-plane byte offset
 int hrn_launch_planes_to_f32(const void* hi, size_t lo_off, float* out, size_t n, hipStream_t stream);
+int hrn_launch_f32_to_planes(const float* in, void* hi, size_t lo_off, size_t n, hipStream_t stream);
 int hrn_launch_stem_pre(const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1, const float* w,
-                        const float* bias, float* out, int M, int H, int W, const float* only_if_nonpos, hipStream_t stream);
+                        const float* bias, float* out, int M, int H, int W, const float* only_if_nonpos, hipStream_t stream, int dt = HRN_F32);
 int hrn_launch_plane_mean(const float* x, float* mean, int planes, size_t hw, hipStream_t stream);
 
 // ---- decoder.hip

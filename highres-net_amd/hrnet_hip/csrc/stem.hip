@@ -290,6 +290,17 @@ __global__ __launch_bounds__(256) void planes_to_f32_kernel(const u32x4* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restrict__ in, u32x4* __restrict__ hi, u32x4* __restrict__ lo, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = *(const f32x4*)(in + i * 8), b = *(const f32x4*)(in + i * 8 + 4);
+        unsigned h[4], l[4];
+        split2_bf16(a[0], a[1], h[0], l[0]); split2_bf16(a[2], a[3], h[1], l[1]);
+        split2_bf16(b[0], b[1], h[2], l[2]); split2_bf16(b[2], b[3], h[3], l[3]);
+        hi[i] = u32x4{h[0], h[1], h[2], h[3]};
+        lo[i] = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
 }  // namespace
 
 int hrn_launch_median(const float* lrs, float* ref, int B, int V, int H, int W, hipStream_t stream) {
@@ -329,9 +340,15 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
 
 // f32, no activation, and only if only_if_nonpos[0] <= 0: the stem's pre-activation for the backward of a PReLU whose slope is not positive
 int hrn_launch_stem_pre(const float* in0, size_t img_stride0, const float* in1, int rep1, size_t img_stride1, const float* w,
-                        const float* bias, float* out, int M, int H, int W, const float* only_if_nonpos, hipStream_t stream) {
+                        const float* bias, float* out, int M, int H, int W, const float* only_if_nonpos, hipStream_t stream, int dt) {
     const size_t patches = (size_t)M * ((H + 3) / 4) * ((W + 31) / 32);
     const int blocks = (int)(patches < 16384 ? patches : 16384);
+    if (dt == HRN_BF16X3) {
+        hipLaunchKernelGGL(stem_kernel<HRN_BF16X3>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, (const float*)nullptr, w, bias,
+                           (const float*)nullptr, (void*)out, M, H, W, only_if_nonpos, (size_t)M * H * W * 64 * 2);
+        HRN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(stem_kernel<HRN_F32>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, (const float*)nullptr, w, bias,
                        (const float*)nullptr, (void*)out, M, H, W, only_if_nonpos, (size_t)0);
     HRN_LAUNCH_CHECK();
@@ -345,6 +362,16 @@ int hrn_launch_planes_to_f32(const void* hi, size_t lo_off, float* out, size_t n
     const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
     HrnProfScope prof("planes_to_f32", 0.0, (double)n * 8, stream);
     hipLaunchKernelGGL(planes_to_f32_kernel, dim3(blocks), dim3(256), 0, stream, (const u32x4*)hi, (const u32x4*)((const unsigned char*)hi + lo_off), out, n8);
+    HRN_LAUNCH_CHECK();
+    return 0;
+}
+
+// f32 -> (hi, lo) bf16 planes
+int hrn_launch_f32_to_planes(const float* in, void* hi, size_t lo_off, size_t n, hipStream_t stream) {
+    HRN_CHECK(n % 8 == 0 && lo_off % 16 == 0, -2, "f32_to_planes: %zu elements / lo offset %zu not aligned", n, lo_off);
+    const size_t n8 = n / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(f32_to_planes_kernel, dim3(blocks), dim3(256), 0, stream, in, (u32x4*)hi, (u32x4*)((unsigned char*)hi + lo_off), n8);
     HRN_LAUNCH_CHECK();
     return 0;
 }

@@ -1,4 +1,6 @@
-// Training path of HRNet (fp32): a forward that keeps what the backward needs, and the backward itself
+// Training path of HRNet (fp32, or bf16x3: every activation / gradient tensor a pair of bf16 planes, three bf16 MFMAs per product - the
+// convolutions, data gradients and weight gradients then run on conv3x3_v6x3.hip / wgrad_x3.hip, the elementwise passes on the same
+// kernels templated on the storage): a forward that keeps what the backward needs, and the backward itself
 // (`srs = fusion_model(lrs, alphas)` ... `loss.backward()`, src/train.py:172-190).
 //
 // Forward (HRNet.py:186-211) is the inference kernel sequence with every intermediate kept in the training workspace:
@@ -28,8 +30,12 @@ struct TrainWs {
     size_t g[5];                            // backward: five gradient buffers of one full activation each
     size_t xpre;                            // backward: a recomputed pre-activation (used only behind a PReLU whose slope is <= 0)
     size_t wt, wtp, zero_bias, scratch;
+    size_t dec_f, dec_g;                    // bf16x3: f32 copies of the fused state and of its gradient (the decoder's backward is the fp32 kernel)
     size_t total;
 };
+
+// bf16x3: a tensor of n elements is a pair of bf16 planes, the lo plane 2 n bytes behind the hi plane (0 for fp32)
+inline size_t lo_of(int dt, size_t n) { return dt == HRN_BF16X3 ? n * 2 : 0; }
 
 int num_cus() { return hrn_device_cus(); }
 
@@ -65,6 +71,8 @@ TrainWs train_ws(int nl, int B, int V, int H, int W) {
     const size_t sd = hrn_decoder_bwd_scratch_bytes(num_cus());
     if (sd > sc) sc = sd;
     w.scratch = take(sc);
+    w.dec_f = take((size_t)B * hw * 64 * 4);
+    w.dec_g = take((size_t)B * hw * 64 * 4);
     w.total = off;
     return w;
 }
@@ -77,31 +85,44 @@ int check_train(int nl, int B, int V, int H, int W) {
 }
 
 // y = conv3x3(x) (+ PReLU) on the forward f32 kernel
-int conv_fwd(int cin, int cout, const void* x, void* y, const void* wpk, const float* bias, const float* slope, int M, int H, int W,
+int conv_fwd(int dt, int cin, int cout, const void* x, void* y, const void* wpk, const float* bias, const float* slope, int M, int H, int W,
              hipStream_t s) {
     ConvParams p = conv_base(M, H, W);
     p.in = x; p.out = y; p.wpk = wpk; p.bias = bias; p.slope = slope;
-    return hrn_launch_conv3x3(HRN_F32, cin, cout, p, s);
+    p.in_lo = lo_of(dt, (size_t)M * H * W * cin); p.out_lo = lo_of(dt, (size_t)M * H * W * cout);
+    return hrn_launch_conv3x3(dt, cin, cout, p, s);
 }
 
 // dx = conv3x3(g, W^T flipped) (+ res): the data gradient of a cin -> cout convolution with raw weights w [cout][cin][3][3]
-int conv_dgrad(int cin, int cout, const float* w, const float* g, float* dx, const float* res, int M, int H, int W, void* tws,
+int conv_dgrad(int dt, int cin, int cout, const float* w, const float* g, float* dx, const float* res, int M, int H, int W, void* tws,
                const TrainWs& L, hipStream_t s) {
-    return hrn_conv_dgrad(cin, cout, w, g, dx, res, M, H, W, (float*)at(tws, L.wt), at(tws, L.wtp), (const float*)at(tws, L.zero_bias), s);
+    return hrn_conv_dgrad(cin, cout, w, g, dx, res, M, H, W, (float*)at(tws, L.wt), at(tws, L.wtp), (const float*)at(tws, L.zero_bias), s, dt);
+}
+
+// dW += the weight gradient of a cin -> cout convolution: x plain [M][H][W][cin], or (x == nullptr) the pair gather of `stack`
+int conv_wgrad(int dt, const float* x, const float* stack, int pair_h, int pair_last, int pair_vs, int Bn, const float* g, int M, int H, int W,
+               int cin, int cout, float* dw, void* sc, int cus, hipStream_t s) {
+    if (dt != HRN_BF16X3) return hrn_launch_conv_wgrad(x, stack, x ? 0 : 1, pair_h, pair_last, pair_vs, g, M, H, W, cin, cout, dw, sc, cus, s);
+    const size_t hw = (size_t)H * W;
+    const size_t x_lo = x ? (size_t)M * hw * cin * 2 : (size_t)Bn * pair_vs * hw * 64 * 2;     // the stack of the level: Bn samples x pair_vs views
+    return hrn_launch_conv_wgrad_x3(x, stack, x_lo, x ? 0 : 1, pair_h, pair_last, pair_vs, g, (size_t)M * hw * cout * 2, M, H, W, cin, cout, dw, sc,
+                                    cus, s);
 }
 
 // z + u for the pair gather z of a level: t2[b*half + i][p][c] = (c < 64 ? s_i : s_partner)[p][c % 64] + u[...]
-__global__ __launch_bounds__(256) void pair_add_kernel(const float* __restrict__ stack, int n_in, int half, int pair_last,
-                                                       const float* __restrict__ u, float* __restrict__ t2, size_t hw, int B) {
+template <bool X3>
+__global__ __launch_bounds__(256) void pair_add_kernel(const void* __restrict__ stack, int n_in, int half, int pair_last,
+                                                       const void* __restrict__ u, void* __restrict__ t2, size_t hw, int B) {
     const size_t total = (size_t)B * half * hw * 32;            // float4 units, 32 per pixel
+    const size_t lo_s = (size_t)B * n_in * hw * 128, lo_u = total * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t pixg = i >> 5;
         const int part = (int)(i & 31);
         const size_t img = pixg / hw, pix = pixg - img * hw;
         const int b = (int)(img / half), v = (int)(img - (size_t)b * half);
         const int src = part < 16 ? v : pair_last - v;
-        const f32x4 z = ((const f32x4*)stack)[(((size_t)b * n_in + src) * hw + pix) * 16 + (part & 15)];
-        ((f32x4*)t2)[i] = z + ((const f32x4*)u)[i];
+        const f32x4 z = act_ld4<X3>(stack, lo_s, (((size_t)b * n_in + src) * hw + pix) * 16 + (part & 15));
+        act_st4<X3>(t2, lo_u, i, z + act_ld4<X3>(u, lo_u, i));
     }
 }
 
@@ -116,28 +137,39 @@ size_t hrn_hrnet_train_workspace_bytes(int num_layers, int B, int V, int H, int 
 
 int hrn_hrnet_forward_train(const void* pk, int nl, int alpha_residual, const float* lrs, const float* alphas, int B, int V, int H, int W,
                             float* sr, void* tws, size_t tws_bytes, void* stream) {
+    return hrn_hrnet_forward_train_dt(pk, HRN_F32, nl, alpha_residual, lrs, alphas, B, V, H, W, sr, tws, tws_bytes, stream);
+}
+
+int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_residual, const float* lrs, const float* alphas, int B, int V,
+                       int H, int W, const float* d_sr, const hrn_hrnet_params* Gr, void* tws, size_t tws_bytes, void* stream) {
+    return hrn_hrnet_backward_dt(pk, HRN_F32, Pr, alpha_residual, lrs, alphas, B, V, H, W, d_sr, Gr, tws, tws_bytes, stream);
+}
+
+int hrn_hrnet_forward_train_dt(const void* pk, int dt, int nl, int alpha_residual, const float* lrs, const float* alphas, int B, int V, int H,
+                               int W, float* sr, void* tws, size_t tws_bytes, void* stream) {
     int rc;
     if ((rc = check_train(nl, B, V, H, W))) return rc;
+    HRN_CHECK(dt == HRN_F32 || dt == HRN_BF16X3, -2, "hrn_hrnet_forward_train: dtype must be HRN_DTYPE_F32 or HRN_DTYPE_BF16X3 (got %d)", dt);
     HRN_CHECK(pk && lrs && alphas && sr && tws, -2, "hrn_hrnet_forward_train: null argument");
     const TrainWs L = train_ws(nl, B, V, H, W);
     HRN_CHECK(tws_bytes >= L.total, -3, "hrn_hrnet_forward_train: workspace too small (%zu < %zu)", tws_bytes, L.total);
-    const HrnetLayout P = hrnet_layout(HRN_F32, nl);
+    const HrnetLayout P = hrnet_layout(dt, nl);
     hipStream_t s = (hipStream_t)stream;
     const size_t hw = (size_t)H * W;
     const int M = B * V;
     float* ref = (float*)at(tws, L.ref);
     if ((rc = hrn_launch_median(lrs, ref, B, V, H, W, s))) return rc;
-    if ((rc = hrn_launch_stem(HRN_F32, lrs, hw, ref, V, hw, nullptr, (const float*)at(pk, P.stem_w), (const float*)at(pk, P.stem_b),
-                              (const float*)at(pk, P.stem_a), at(tws, L.a[0]), M, H, W, s))) return rc;
+    if ((rc = hrn_launch_stem(dt, lrs, hw, ref, V, hw, nullptr, (const float*)at(pk, P.stem_w), (const float*)at(pk, P.stem_b),
+                              (const float*)at(pk, P.stem_a), at(tws, L.a[0]), M, H, W, s, lo_of(dt, (size_t)M * hw * 64)))) return rc;
     for (int l = 0; l < nl; ++l) {
-        if ((rc = conv_fwd(64, 64, at(tws, L.a[l]), at(tws, L.h[l]), at(pk, P.enc_w[2 * l]), (const float*)at(pk, P.enc_b[2 * l]),
+        if ((rc = conv_fwd(dt, 64, 64, at(tws, L.a[l]), at(tws, L.h[l]), at(pk, P.enc_w[2 * l]), (const float*)at(pk, P.enc_b[2 * l]),
                            (const float*)at(pk, P.enc_a[2 * l]), M, H, W, s))) return rc;
-        if ((rc = conv_fwd(64, 64, at(tws, L.h[l]), at(tws, L.r[l]), at(pk, P.enc_w[2 * l + 1]), (const float*)at(pk, P.enc_b[2 * l + 1]),
+        if ((rc = conv_fwd(dt, 64, 64, at(tws, L.h[l]), at(tws, L.r[l]), at(pk, P.enc_w[2 * l + 1]), (const float*)at(pk, P.enc_b[2 * l + 1]),
                            (const float*)at(pk, P.enc_a[2 * l + 1]), M, H, W, s))) return rc;
         if ((rc = hrn_launch_add((const float*)at(tws, L.a[l]), (const float*)at(tws, L.r[l]), (float*)at(tws, L.a[l + 1]),
-                                 (size_t)M * hw * 64, s))) return rc;
+                                 (size_t)M * hw * 64, s, dt))) return rc;
     }
-    if ((rc = conv_fwd(64, 64, at(tws, L.a[nl]), at(tws, L.stack[0]), at(pk, P.encf_w), (const float*)at(pk, P.encf_b), nullptr, M, H, W, s)))
+    if ((rc = conv_fwd(dt, 64, 64, at(tws, L.a[nl]), at(tws, L.stack[0]), at(pk, P.encf_w), (const float*)at(pk, P.encf_b), nullptr, M, H, W, s)))
         return rc;
     for (int t = 0; t < L.T; ++t) {
         const int n = L.n_in[t], half = n / 2, pair_last = n - (n & 1) - 1;
@@ -145,31 +177,36 @@ int hrn_hrnet_forward_train(const void* pk, int nl, int alpha_residual, const fl
         ConvParams a = conv_base(B * half, H, W);
         a.in_pair = 1; a.stack = st; a.pair_h = half; a.pair_last = pair_last; a.pair_vs = n;
         a.out = at(tws, L.t1[t]);
+        a.stack_lo = lo_of(dt, (size_t)B * n * hw * 64); a.out_lo = lo_of(dt, (size_t)B * half * hw * 128);
         a.wpk = at(pk, P.fres_w[0]); a.bias = (const float*)at(pk, P.fres_b[0]); a.slope = (const float*)at(pk, P.fres_a[0]);
-        if ((rc = hrn_launch_conv3x3(HRN_F32, 128, 128, a, s))) return rc;
-        if ((rc = conv_fwd(128, 128, at(tws, L.t1[t]), at(tws, L.u[t]), at(pk, P.fres_w[1]), (const float*)at(pk, P.fres_b[1]),
+        if ((rc = hrn_launch_conv3x3(dt, 128, 128, a, s))) return rc;
+        if ((rc = conv_fwd(dt, 128, 128, at(tws, L.t1[t]), at(tws, L.u[t]), at(pk, P.fres_w[1]), (const float*)at(pk, P.fres_b[1]),
                            (const float*)at(pk, P.fres_a[1]), B * half, H, W, s))) return rc;
         {
             const size_t total4 = (size_t)B * half * hw * 32;
             size_t grid = (total4 + 255) / 256;
             if (grid > 4096) grid = 4096;
-            hipLaunchKernelGGL(pair_add_kernel, dim3((unsigned)grid), dim3(256), 0, s, st, n, half, pair_last, (const float*)at(tws, L.u[t]),
-                               (float*)at(tws, L.t2[t]), hw, B);
+            if (dt == HRN_BF16X3) hipLaunchKernelGGL(pair_add_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, (const void*)st, n, half, pair_last, (const void*)at(tws, L.u[t]),
+                                                     (void*)at(tws, L.t2[t]), hw, B);
+            else hipLaunchKernelGGL(pair_add_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, (const void*)st, n, half, pair_last, (const void*)at(tws, L.u[t]),
+                                    (void*)at(tws, L.t2[t]), hw, B);
             HRN_LAUNCH_CHECK();
         }
-        if ((rc = conv_fwd(128, 64, at(tws, L.t2[t]), at(tws, L.f[t]), at(pk, P.fout_w), (const float*)at(pk, P.fout_b),
+        if ((rc = conv_fwd(dt, 128, 64, at(tws, L.t2[t]), at(tws, L.f[t]), at(pk, P.fout_w), (const float*)at(pk, P.fout_b),
                            (const float*)at(pk, P.fout_a), B * half, H, W, s))) return rc;
         if ((rc = hrn_launch_fuse_update(st, n, (const float*)at(tws, L.f[t]), alphas, V, pair_last, half, alpha_residual,
-                                         (float*)at(tws, L.stack[t + 1]), hw, B, s))) return rc;
+                                         (float*)at(tws, L.stack[t + 1]), hw, B, s, dt))) return rc;
     }
     // views left after the last level: 1 (or V itself for V == 1); torch.mean over them (HRNet.py:134) is the identity
-    return hrn_launch_decoder(HRN_F32, at(tws, L.stack[L.T]), at(pk, P.dec_w), (const float*)at(pk, P.dec_b), (const float*)at(pk, P.dec_a),
-                              (const float*)at(pk, P.fin_w), (const float*)at(pk, P.fin_b), sr, B, H, W, s);
+    return hrn_launch_decoder(dt, at(tws, L.stack[L.T]), at(pk, P.dec_w), (const float*)at(pk, P.dec_b), (const float*)at(pk, P.dec_a),
+                              (const float*)at(pk, P.fin_w), (const float*)at(pk, P.fin_b), sr, B, H, W, s,
+                              lo_of(dt, (size_t)B * L.n_in[L.T] * hw * 64));
 }
 
-int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_residual, const float* lrs, const float* alphas, int B, int V,
-                       int H, int W, const float* d_sr, const hrn_hrnet_params* Gr, void* tws, size_t tws_bytes, void* stream) {
+int hrn_hrnet_backward_dt(const void* pk, int dt, const hrn_hrnet_params* Pr, int alpha_residual, const float* lrs, const float* alphas, int B,
+                          int V, int H, int W, const float* d_sr, const hrn_hrnet_params* Gr, void* tws, size_t tws_bytes, void* stream) {
     int rc;
+    HRN_CHECK(dt == HRN_F32 || dt == HRN_BF16X3, -2, "hrn_hrnet_backward: dtype must be HRN_DTYPE_F32 or HRN_DTYPE_BF16X3 (got %d)", dt);
     HRN_CHECK(pk && Pr && Gr && lrs && alphas && d_sr && tws, -2, "hrn_hrnet_backward: null argument");
     const int nl = Pr->num_layers;
     if ((rc = check_train(nl, B, V, H, W))) return rc;
@@ -187,18 +224,29 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
     // PReLU backward works from the stored post-activation while the slope is positive.  For a slope <= 0 (the reference allows any)
     // the pre-activation is recomputed into `xpre` by the forward kernel without activation - a launch that does nothing unless the
     // slope on the device says so (ConvParams::only_if_nonpos): no host round trip, ~3 us per PReLU in the usual case.
-    const HrnetLayout P = hrnet_layout(HRN_F32, nl);
+    const HrnetLayout P = hrnet_layout(dt, nl);
     float* xpre = (float*)at(tws, L.xpre);
     auto pre = [&](int cin, int cout, const void* x, const void* wpk, const float* bias, const float* slope, int Mi) -> int {
         ConvParams q = conv_base(Mi, H, W);
         q.in = x; q.out = xpre; q.wpk = wpk; q.bias = bias; q.only_if_nonpos = slope;
-        return hrn_launch_conv3x3(HRN_F32, cin, cout, q, s);
+        q.in_lo = lo_of(dt, (size_t)Mi * hw * cin); q.out_lo = lo_of(dt, (size_t)Mi * hw * cout);
+        return hrn_launch_conv3x3(dt, cin, cout, q, s);
     };
 
     // ---- decoder: d_sr -> d stack_T (one view left)                                  HRNet.py:147-156,167-169
     float* dsn = G[0];                      // gradient of the views leaving the current level
-    if ((rc = hrn_launch_decoder_bwd((const float*)at(tws, L.stack[L.T]), d_sr, Pr->dec_w, Pr->dec_b, Pr->dec_a, Pr->fin_w, dsn,
-                                     mut(Gr->dec_w), mut(Gr->dec_b), mut(Gr->dec_a), mut(Gr->fin_w), mut(Gr->fin_b), B, H, W, sc, cus, s)))
+    if (dt == HRN_BF16X3) {
+        // the decoder's backward is the fp32 kernel (33 MB of state at the training shape): the fused state as f32, its gradient back as planes
+        const size_t nf = (size_t)B * L.n_in[L.T] * hw * 64;
+        float* ff = (float*)at(tws, L.dec_f);
+        float* fg = (float*)at(tws, L.dec_g);
+        if ((rc = hrn_launch_planes_to_f32(at(tws, L.stack[L.T]), nf * 2, ff, nf, s))) return rc;
+        if ((rc = hrn_launch_decoder_bwd(ff, d_sr, Pr->dec_w, Pr->dec_b, Pr->dec_a, Pr->fin_w, fg,
+                                         mut(Gr->dec_w), mut(Gr->dec_b), mut(Gr->dec_a), mut(Gr->fin_w), mut(Gr->fin_b), B, H, W, sc, cus, s)))
+            return rc;
+        if ((rc = hrn_launch_f32_to_planes(fg, dsn, nf * 2, nf, s))) return rc;
+    } else if ((rc = hrn_launch_decoder_bwd((const float*)at(tws, L.stack[L.T]), d_sr, Pr->dec_w, Pr->dec_b, Pr->dec_a, Pr->fin_w, dsn,
+                                            mut(Gr->dec_w), mut(Gr->dec_b), mut(Gr->dec_a), mut(Gr->fin_w), mut(Gr->fin_b), B, H, W, sc, cus, s)))
         return rc;
 
     // ---- fusion levels, last to first                                                HRNet.py:113-132
@@ -211,57 +259,58 @@ int hrn_hrnet_backward(const void* pk, const hrn_hrnet_params* Pr, int alpha_res
         float* x1 = G[2];                   // df / gC            [Mh][hw][64]
         float* y3 = G[3];                   // d t1 / gA          [Mh][hw][128]
         float* y2 = G[4];                   // gB, later dz       [Mh][hw][128]
-        if ((rc = hrn_launch_fuse_df(dsn, alphas, V, pair_last, half, alpha_residual, x1, hw, B, s))) return rc;
+        if ((rc = hrn_launch_fuse_df(dsn, alphas, V, pair_last, half, alpha_residual, x1, hw, B, s, dt))) return rc;
         // f = PReLU(convC(t2))
         if ((rc = pre(128, 64, at(tws, L.t2[t]), at(pk, P.fout_w), (const float*)at(pk, P.fout_b), Pr->fuse_out_a, Mh))) return rc;
-        if ((rc = hrn_launch_prelu_bwd_bias(x1, (const float*)at(tws, L.f[t]), xpre, Pr->fuse_out_a, x1, (size_t)Mh * hw, 64, mut(Gr->fuse_out_a), mut(Gr->fuse_out_b), sc, s))) return rc;
-        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t2[t]), nullptr, 0, 0, 0, 0, x1, Mh, H, W, 128, 64, mut(Gr->fuse_out_w), sc, cus, s))) return rc;
-        if ((rc = conv_dgrad(128, 64, Pr->fuse_out_w, x1, y1, nullptr, Mh, H, W, tws, L, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(x1, (const float*)at(tws, L.f[t]), xpre, Pr->fuse_out_a, x1, (size_t)Mh * hw, 64, mut(Gr->fuse_out_a), mut(Gr->fuse_out_b), sc, s, dt))) return rc;
+        if ((rc = conv_wgrad(dt, (const float*)at(tws, L.t2[t]), nullptr, 0, 0, 0, B, x1, Mh, H, W, 128, 64, mut(Gr->fuse_out_w), sc, cus, s))) return rc;
+        if ((rc = conv_dgrad(dt, 128, 64, Pr->fuse_out_w, x1, y1, nullptr, Mh, H, W, tws, L, s))) return rc;
         // t2 = z + u, u = PReLU(convB(t1))
         if ((rc = pre(128, 128, at(tws, L.t1[t]), at(pk, P.fres_w[1]), (const float*)at(pk, P.fres_b[1]), Pr->fuse_res_a[1], Mh))) return rc;
-        if ((rc = hrn_launch_prelu_bwd_bias(y1, (const float*)at(tws, L.u[t]), xpre, Pr->fuse_res_a[1], y2, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[1]), mut(Gr->fuse_res_b[1]), sc, s))) return rc;
-        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.t1[t]), nullptr, 0, 0, 0, 0, y2, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[1]), sc, cus, s))) return rc;
-        if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[1], y2, y3, nullptr, Mh, H, W, tws, L, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(y1, (const float*)at(tws, L.u[t]), xpre, Pr->fuse_res_a[1], y2, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[1]), mut(Gr->fuse_res_b[1]), sc, s, dt))) return rc;
+        if ((rc = conv_wgrad(dt, (const float*)at(tws, L.t1[t]), nullptr, 0, 0, 0, B, y2, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[1]), sc, cus, s))) return rc;
+        if ((rc = conv_dgrad(dt, 128, 128, Pr->fuse_res_w[1], y2, y3, nullptr, Mh, H, W, tws, L, s))) return rc;
         // t1 = PReLU(convA(z))
         {
             ConvParams q = conv_base(Mh, H, W);
             q.in_pair = 1; q.stack = st; q.pair_h = half; q.pair_last = pair_last; q.pair_vs = n;
             q.out = xpre; q.wpk = at(pk, P.fres_w[0]); q.bias = (const float*)at(pk, P.fres_b[0]); q.only_if_nonpos = Pr->fuse_res_a[0];
-            if ((rc = hrn_launch_conv3x3(HRN_F32, 128, 128, q, s))) return rc;
+            q.stack_lo = lo_of(dt, (size_t)B * n * hw * 64); q.out_lo = lo_of(dt, (size_t)Mh * hw * 128);
+            if ((rc = hrn_launch_conv3x3(dt, 128, 128, q, s))) return rc;
         }
-        if ((rc = hrn_launch_prelu_bwd_bias(y3, (const float*)at(tws, L.t1[t]), xpre, Pr->fuse_res_a[0], y3, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[0]), mut(Gr->fuse_res_b[0]), sc, s))) return rc;
-        if ((rc = hrn_launch_conv_wgrad(nullptr, st, 1, half, pair_last, n, y3, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[0]), sc, cus, s))) return rc;
-        if ((rc = conv_dgrad(128, 128, Pr->fuse_res_w[0], y3, y2, y1, Mh, H, W, tws, L, s))) return rc;     // dz = d t2 + dgradA(gA)
+        if ((rc = hrn_launch_prelu_bwd_bias(y3, (const float*)at(tws, L.t1[t]), xpre, Pr->fuse_res_a[0], y3, (size_t)Mh * hw, 128, mut(Gr->fuse_res_a[0]), mut(Gr->fuse_res_b[0]), sc, s, dt))) return rc;
+        if ((rc = conv_wgrad(dt, nullptr, st, half, pair_last, n, B, y3, Mh, H, W, 128, 128, mut(Gr->fuse_res_w[0]), sc, cus, s))) return rc;
+        if ((rc = conv_dgrad(dt, 128, 128, Pr->fuse_res_w[0], y3, y2, y1, Mh, H, W, tws, L, s))) return rc;     // dz = d t2 + dgradA(gA)
         // dz -> the two views of each pair (+ the alice pass-through)
-        if ((rc = hrn_launch_fuse_scatter(dsn, y2, n, half, pair_last, alpha_residual, ds, hw, B, s))) return rc;
+        if ((rc = hrn_launch_fuse_scatter(dsn, y2, n, half, pair_last, alpha_residual, ds, hw, B, s, dt))) return rc;
         float* tmp = G[0]; G[0] = G[1]; G[1] = tmp;
         dsn = G[0];
     }
 
     // ---- encoder                                                                     HRNet.py:51-60,62-74
     float* dA = G[1];
-    if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.a[nl]), nullptr, 0, 0, 0, 0, dsn, M, H, W, 64, 64, mut(Gr->enc_final_w), sc, cus, s))) return rc;
-    if ((rc = hrn_launch_colsum(dsn, (size_t)M * hw, 64, mut(Gr->enc_final_b), sc, s))) return rc;
-    if ((rc = conv_dgrad(64, 64, Pr->enc_final_w, dsn, dA, nullptr, M, H, W, tws, L, s))) return rc;
+    if ((rc = conv_wgrad(dt, (const float*)at(tws, L.a[nl]), nullptr, 0, 0, 0, B, dsn, M, H, W, 64, 64, mut(Gr->enc_final_w), sc, cus, s))) return rc;
+    if ((rc = hrn_launch_colsum(dsn, (size_t)M * hw, 64, mut(Gr->enc_final_b), sc, s, dt))) return rc;
+    if ((rc = conv_dgrad(dt, 64, 64, Pr->enc_final_w, dsn, dA, nullptr, M, H, W, tws, L, s))) return rc;
     float* e2 = G[2];
     float* e3 = G[3];
     for (int l = nl - 1; l >= 0; --l) {
         // a_{l+1} = a_l + r_l,  r_l = PReLU(conv2(h_l)),  h_l = PReLU(conv1(a_l))
         if ((rc = pre(64, 64, at(tws, L.h[l]), at(pk, P.enc_w[2 * l + 1]), (const float*)at(pk, P.enc_b[2 * l + 1]), Pr->enc_res_a[2 * l + 1], M))) return rc;
-        if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.r[l]), xpre, Pr->enc_res_a[2 * l + 1], e2, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l + 1]), mut(Gr->enc_res_b[2 * l + 1]), sc, s))) return rc;
-        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.h[l]), nullptr, 0, 0, 0, 0, e2, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l + 1]), sc, cus, s))) return rc;
-        if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l + 1], e2, e3, nullptr, M, H, W, tws, L, s))) return rc;
+        if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.r[l]), xpre, Pr->enc_res_a[2 * l + 1], e2, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l + 1]), mut(Gr->enc_res_b[2 * l + 1]), sc, s, dt))) return rc;
+        if ((rc = conv_wgrad(dt, (const float*)at(tws, L.h[l]), nullptr, 0, 0, 0, B, e2, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l + 1]), sc, cus, s))) return rc;
+        if ((rc = conv_dgrad(dt, 64, 64, Pr->enc_res_w[2 * l + 1], e2, e3, nullptr, M, H, W, tws, L, s))) return rc;
         if ((rc = pre(64, 64, at(tws, L.a[l]), at(pk, P.enc_w[2 * l]), (const float*)at(pk, P.enc_b[2 * l]), Pr->enc_res_a[2 * l], M))) return rc;
-        if ((rc = hrn_launch_prelu_bwd_bias(e3, (const float*)at(tws, L.h[l]), xpre, Pr->enc_res_a[2 * l], e3, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l]), mut(Gr->enc_res_b[2 * l]), sc, s))) return rc;
-        if ((rc = hrn_launch_conv_wgrad((const float*)at(tws, L.a[l]), nullptr, 0, 0, 0, 0, e3, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l]), sc, cus, s))) return rc;
-        if ((rc = conv_dgrad(64, 64, Pr->enc_res_w[2 * l], e3, e2, dA, M, H, W, tws, L, s))) return rc;       // d a_l = d a_{l+1} + dgrad1(g1)
+        if ((rc = hrn_launch_prelu_bwd_bias(e3, (const float*)at(tws, L.h[l]), xpre, Pr->enc_res_a[2 * l], e3, (size_t)M * hw, 64, mut(Gr->enc_res_a[2 * l]), mut(Gr->enc_res_b[2 * l]), sc, s, dt))) return rc;
+        if ((rc = conv_wgrad(dt, (const float*)at(tws, L.a[l]), nullptr, 0, 0, 0, B, e3, M, H, W, 64, 64, mut(Gr->enc_res_w[2 * l]), sc, cus, s))) return rc;
+        if ((rc = conv_dgrad(dt, 64, 64, Pr->enc_res_w[2 * l], e3, e2, dA, M, H, W, tws, L, s))) return rc;       // d a_l = d a_{l+1} + dgrad1(g1)
         float* tmp = dA; dA = e2; e2 = tmp;
     }
     // stem: a_0 = PReLU(conv(cat(view, reference frame)))                               HRNet.py:200-204, :51-53
     if ((rc = hrn_launch_stem_pre(lrs, hw, (const float*)at(tws, L.ref), V, hw, (const float*)at(pk, P.stem_w), (const float*)at(pk, P.stem_b), xpre, M, H, W,
-                                  Pr->enc_init_a, s))) return rc;
-    if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.a[0]), xpre, Pr->enc_init_a, dA, (size_t)M * hw, 64, mut(Gr->enc_init_a), mut(Gr->enc_init_b), sc, s))) return rc;
-    return hrn_launch_stem_wgrad(lrs, hw, (const float*)at(tws, L.ref), V, hw, dA, M, H, W, mut(Gr->enc_init_w), sc, cus, s);
+                                  Pr->enc_init_a, s, dt))) return rc;
+    if ((rc = hrn_launch_prelu_bwd_bias(dA, (const float*)at(tws, L.a[0]), xpre, Pr->enc_init_a, dA, (size_t)M * hw, 64, mut(Gr->enc_init_a), mut(Gr->enc_init_b), sc, s, dt))) return rc;
+    return hrn_launch_stem_wgrad(lrs, hw, (const float*)at(tws, L.ref), V, hw, dA, M, H, W, mut(Gr->enc_init_w), sc, cus, s, dt);
 }
 
 }  // extern "C"

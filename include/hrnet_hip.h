@@ -114,6 +114,15 @@ int hrn_hrnet_forward_train(const void* packed, int num_layers, int alpha_residu
 int hrn_hrnet_backward(const void* packed, const hrn_hrnet_params* params, int alpha_residual, const float* lrs,
                        const float* alphas, int B, int V, int H, int W, const float* d_sr, const hrn_hrnet_params* grads,
                        void* train_ws, size_t train_ws_bytes, void* stream);
+/* The same with a dtype: HRN_DTYPE_F32 (what the two entry points above run) or HRN_DTYPE_BF16X3 - every activation and gradient
+ * tensor of the workspace a pair of bf16 planes, three bf16 MFMAs per product in the convolutions, their data gradients and their
+ * weight gradients (same workspace size; `packed` is then the HRN_DTYPE_BF16X3 blob).  Parameters, gradients, lrs, sr, d_sr: f32. */
+int hrn_hrnet_forward_train_dt(const void* packed, int dtype, int num_layers, int alpha_residual, const float* lrs,
+                               const float* alphas, int B, int V, int H, int W, float* sr, void* train_ws, size_t train_ws_bytes,
+                               void* stream);
+int hrn_hrnet_backward_dt(const void* packed, int dtype, const hrn_hrnet_params* params, int alpha_residual, const float* lrs,
+                          const float* alphas, int B, int V, int H, int W, const float* d_sr, const hrn_hrnet_params* grads,
+                          void* train_ws, size_t train_ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ ShiftNet */
 typedef struct hrn_shiftnet_params {

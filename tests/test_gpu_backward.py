@@ -16,7 +16,12 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _fresh_model(alpha_residual=True, seed=1234, slopes=None):
+_SLOPE_KEYS = ["encode.init_layer.1.weight", "encode.res_layers.0.block.1.weight", "encode.res_layers.0.block.3.weight",
+               "encode.res_layers.1.block.1.weight", "encode.res_layers.1.block.3.weight", "fuse.fuse.0.block.1.weight",
+               "fuse.fuse.0.block.3.weight", "fuse.fuse.2.weight", "decode.deconv.1.weight"]
+
+
+def _fresh_model(alpha_residual=True, seed=1234, slopes=None, precision="fp32"):
     from DeepNetworks.HRNet import HRNet
     cfg = {k: dict(v) for k, v in weights.HRNET_CONFIG.items()}
     cfg["recursive"]["alpha_residual"] = alpha_residual
@@ -24,6 +29,7 @@ def _fresh_model(alpha_residual=True, seed=1234, slopes=None):
     st = weights.to_torch_state(weights.hrnet_state(seed))
     st.update({k: torch.full_like(st[k], v) for k, v in (slopes or {}).items()})
     m.load_state_dict(st)
+    m.precision = precision
     return m.cuda().train()
 
 
@@ -53,15 +59,24 @@ def _oracle_grads(lrs, alphas, cot, alpha_residual, seed=1234, slopes=None):
     (2, 6, 16, 6, False),       # alpha_residual = false branch (HRNet.py:123)
     (2, 1, 16, 1, True),        # a single view: no fusion level at all
 ])
-def test_hrnet_backward_vs_autograd_oracle(B, V, S, n_real, alpha_residual):
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_hrnet_backward_vs_autograd_oracle(B, V, S, n_real, alpha_residual, prec):
+    """prec "bf16x3": the same check for the split-bf16 training mode (forward, data gradients and weight gradients on the bf16 matrix
+    cores, three MFMAs per product; activations and gradients as hi/lo bf16 pairs, ~2^-16 per product instead of fp32's 2^-24).  A
+    PReLU's derivative jumps at zero: the handful of activations whose sign differs between a ~1e-5 forward and the fp64 oracle each
+    move a weight gradient by ~1 / sqrt(#pixels) - the exact-fp32 path shows the same 2e-3..1e-2 at 64 x 64 (tools/x3_grad_debug.py) -,
+    so the KERNELS are pinned with every PReLU slope at 1 (the network is then linear in its activations and nothing can flip:
+    measured 1.4e-5, held to the fp32 bounds), and `test_bf16x3_gradients_with_default_slopes` bounds the flips."""
+    k_tol = 1.0
+    slopes = None if prec == "fp32" else {k: 1.0 for k in _SLOPE_KEYS}
     lrs, alphas, _ = synth.make_batch(5, B, V, S, n_real)
     rng = np.random.Generator(np.random.PCG64(77))
     cot = rng.standard_normal((B, 1, 3 * S, 3 * S)).astype(np.float32)
-    want_sr, want = _oracle_grads(lrs, alphas, cot, alpha_residual)
-    m = _fresh_model(alpha_residual)
+    want_sr, want = _oracle_grads(lrs, alphas, cot, alpha_residual, slopes=slopes)
+    m = _fresh_model(alpha_residual, precision=prec, slopes=slopes)
     sr = m(util.dev(lrs), util.dev(alphas))
     assert sr.requires_grad
-    assert util.rel_err(sr.detach().cpu().numpy(), want_sr) <= 2e-5
+    assert util.rel_err(sr.detach().cpu().numpy(), want_sr) <= (2e-5 if prec == "fp32" else 1e-4)
     (sr * util.dev(cot)).sum().backward()
     # PReLU-slope / final-bias gradients are sums of ~1e4..1e5 signed terms that can cancel to a small net value (the stem's at
     # V = 1: 0.026 against a sum of |terms| in the tens).  A float32 implementation carries each TERM to ~1e-6..1e-5 relative, so
@@ -72,16 +87,32 @@ def test_hrnet_backward_vs_autograd_oracle(B, V, S, n_real, alpha_residual):
         assert p.grad is not None, k
         got = p.grad.cpu().numpy()
         if p.numel() == 1:
-            bound = 2e-5 * abs_terms.get(k, 0.0) + 1e-12
+            bound = 2e-5 * k_tol * abs_terms.get(k, 0.0) + 1e-12
             assert abs(float(got.ravel()[0]) - float(want[k].ravel()[0])) <= bound, (k, got, want[k], abs_terms.get(k))
         else:
             e = util.rel_err(got, want[k])
-            assert e <= 2e-4, (k, e)
+            assert e <= 2e-4 * k_tol, (k, e)
     # a second backward pass accumulates into .grad like autograd does
     sr2 = m(util.dev(lrs), util.dev(alphas))
     (sr2 * util.dev(cot)).sum().backward()
     k0, p0 = next(iter(m.named_parameters()))
-    assert util.rel_err(p0.grad.cpu().numpy(), 2 * want[k0]) <= 2e-4
+    assert util.rel_err(p0.grad.cpu().numpy(), 2 * want[k0]) <= 2e-4 * k_tol
+
+
+def test_bf16x3_gradients_with_default_slopes():
+    """The split-bf16 training mode at the reference's PReLU slopes (0.25): gradients within 3e-2 of the fp64 oracle's max-norm per
+    tensor (sign flips of near-zero activations, see above; measured 2e-4 .. 3e-3 here), the forward within 1e-4."""
+    lrs, alphas, _ = synth.make_batch(5, 2, 4, 16, 4)
+    rng = np.random.Generator(np.random.PCG64(77))
+    cot = rng.standard_normal((2, 1, 48, 48)).astype(np.float32)
+    want_sr, want = _oracle_grads(lrs, alphas, cot, True)
+    m = _fresh_model(True, precision="bf16x3")
+    sr = m(util.dev(lrs), util.dev(alphas))
+    assert util.rel_err(sr.detach().cpu().numpy(), want_sr) <= 1e-4
+    (sr * util.dev(cot)).sum().backward()
+    for k, p in m.named_parameters():
+        if p.numel() > 1:
+            assert util.rel_err(p.grad.cpu().numpy(), want[k]) <= 3e-2, k
 
 
 def test_backward_twice_with_retain_graph():

@@ -387,9 +387,9 @@ def test_entry_points_are_registered_torch_ops():
     mt = util.hip_hrnet("fp32", seed=77).train()
     params = [p for _, p in mt.named_parameters()]
     p32 = mt._packed_f32()
-    torch.library.opcheck(ops.hrnet_forward_train.default, (p32, x, a, params, 2, True), test_utils=full)
-    sr, tws = ops.hrnet_forward_train(p32, x, a, params, 2, True)
-    torch.library.opcheck(ops.hrnet_backward.default, (p32, [p.detach() for p in params], x, a, torch.rand_like(sr), tws, 2, True), test_utils=basic)
+    torch.library.opcheck(ops.hrnet_forward_train.default, (p32, x, a, params, 2, True, binding.F32), test_utils=full)
+    sr, tws = ops.hrnet_forward_train(p32, x, a, params, 2, True, binding.F32)
+    torch.library.opcheck(ops.hrnet_backward.default, (p32, [p.detach() for p in params], x, a, torch.rand_like(sr), tws, 2, True, binding.F32), test_utils=basic)
     mt.eval()
     # ShiftNet training pair
     from DeepNetworks.ShiftNet import ShiftNet
