@@ -688,11 +688,14 @@ def _(packed, params, lrs, alphas, d_sr, tws, num_layers, alpha_residual, dtype)
 def _hrnet_train_setup(ctx, inputs, output):
     packed, lrs, alphas, params, num_layers, alpha_residual, dtype = inputs
     ctx.num_layers, ctx.alpha_residual, ctx.n, ctx.dtype = num_layers, alpha_residual, len(params), dtype
+    ctx.set_materialize_grads(False)          # (or autograd hands the backward a zero-filled "gradient" of the 20 GB workspace output)
     ctx.save_for_backward(packed, lrs, alphas, output[1], *params)
 
 
 def _hrnet_train_backward(ctx, d_sr, _d_tws):
     packed, lrs, alphas, tws, *params = ctx.saved_tensors
+    if d_sr is None:
+        return None, None, None, [None] * len(params), None, None, None
     # (tws.data: the backward's scratch buffers live in tws too, so the op declares it mutated; through an alias with its own version
     # counter the saved tensor stays valid for a second backward pass - backward(retain_graph=True), the kept intermediates are only read)
     grads = torch.ops.hrnet_hip.hrnet_backward(packed, params, lrs, alphas, d_sr, tws.data, ctx.num_layers, ctx.alpha_residual, ctx.dtype)
@@ -747,11 +750,14 @@ def _(params, x, dropout_mask, d_theta, tws, need_input_grad):
 def _shiftnet_train_setup(ctx, inputs, output):
     packed, x, params, bn_running, momentum, dropout_mask = inputs
     ctx.np, ctx.has_mask = len(params), dropout_mask is not None
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(x, output[1], *params, *([dropout_mask] if dropout_mask is not None else []))
 
 
 def _shiftnet_train_backward(ctx, d_theta, _d_tws, _d_running):
     x, tws, *rest = ctx.saved_tensors
+    if d_theta is None:
+        return None, None, [None] * ctx.np, [None] * len(SHIFTNET_BUFFER_NAMES), None, None
     params = rest[:ctx.np]
     mask = rest[ctx.np] if ctx.has_mask else None
     need_x = ctx.needs_input_grad[1]
@@ -778,10 +784,13 @@ def _(img, shift, d_out):
 
 def _lanczos_setup(ctx, inputs, output):
     ctx.save_for_backward(*inputs)
+    ctx.set_materialize_grads(False)
 
 
 def _lanczos_backward(ctx, d_out):
     img, shift = ctx.saved_tensors
+    if d_out is None:
+        return None, None
     d_img, d_shift = torch.ops.hrnet_hip.lanczos_shift_backward(img, shift, d_out)
     return (d_img.to(img.dtype) if ctx.needs_input_grad[0] else None), (d_shift.to(shift.dtype) if ctx.needs_input_grad[1] else None)
 
@@ -814,10 +823,13 @@ def _(srs, hrs, hr_maps, stats, d_out, metric, crop):
 def _loss_setup(ctx, inputs, output):
     srs, hrs, hr_maps, ctx.metric, ctx.crop = inputs
     ctx.save_for_backward(srs, hrs, hr_maps, output[1])
+    ctx.set_materialize_grads(False)
 
 
 def _loss_backward(ctx, d_out, _d_stats):
     srs, hrs, hr_maps, stats = ctx.saved_tensors
+    if d_out is None:
+        return None, None, None, None, None
     return torch.ops.hrnet_hip.get_loss_backward(srs, hrs, hr_maps, stats, d_out, ctx.metric, ctx.crop), None, None, None, None
 
 

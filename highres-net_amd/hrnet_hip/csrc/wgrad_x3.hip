@@ -17,6 +17,10 @@
 #include "kernels.h"
 #include "backward.h"
 
+#ifndef WGX_ABL
+#define WGX_ABL 0       // timing-only ablations (results WRONG): 1 no DMA | 2 no transposed reads | 4 no MFMA | 8 no row barrier
+#endif
+
 namespace {
 
 constexpr int XPX = 40, GPX = 32;                            // pixels per LDS row image (x: 34 used)
@@ -116,40 +120,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradX3Para
             const int px = 8 * w + (lq >> 3), gx = x0 + px;
             gv = gx < W ? (unsigned)gx * gpitch + gcb + (unsigned)((((lq & 7) ^ swz_w(px))) << 4) : OOBW;
         }
-        auto dma_x = [&](int row) __attribute__((always_inline)) {              // image row `row` of x -> ring slot (row + 1) % XRING
-            const bool ok = (unsigned)row < (unsigned)H;
-            const unsigned soff = ok ? (unsigned)row * (unsigned)W * xpitch : 0u;
-            const int slot = (row + 1) % XRING;
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? rx1 : rx0, (lds_ptr_w)(smem + slot * XSLOT + pl * XPLANE + w * 1024), 16, ok ? xv[0] : OOBW, soff, 0, 0);
-                if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? rx1 : rx0, (lds_ptr_w)(smem + slot * XSLOT + pl * XPLANE + 4 * 1024), 16, ok ? xv[1] : OOBW, soff, 0, 0);
+        // one DMA instruction of an image row: item 0 / 1 = x piece w of plane 0 / 1, 2 / 3 = g piece w of plane 0 / 1, 4 / 5 = x piece 4 of
+        // plane 0 / 1 (wave 0 only).  x row `row` -> ring slot (row + 1) % XRING, g row `row` -> slot row % GRING
+        auto dma_item = [&](int it, int xrow, int grow) __attribute__((always_inline)) {
+            if (WGX_ABL & 1) return;
+            const int pl = it & 1;
+            if (it == 2 || it == 3) {
+                const bool ok = grow < H;
+                const unsigned soff = ok ? (unsigned)grow * (unsigned)W * gpitch : 0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? rg1 : rg0, (lds_ptr_w)(smem + OFF_G + (grow % GRING) * GSLOT + pl * GPLANE + w * 1024), 16,
+                                                         ok ? gv : OOBW, soff, 0, 0);
+            } else {
+                if (it >= 4 && w != 0) return;
+                const bool ok = (unsigned)xrow < (unsigned)H;
+                const unsigned soff = ok ? (unsigned)xrow * (unsigned)W * xpitch : 0u;
+                const int piece = it >= 4 ? 4 : w;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? rx1 : rx0, (lds_ptr_w)(smem + ((xrow + 1) % XRING) * XSLOT + pl * XPLANE + piece * 1024), 16,
+                                                         ok ? (it >= 4 ? xv[1] : xv[0]) : OOBW, soff, 0, 0);
             }
         };
-        auto dma_g = [&](int row) __attribute__((always_inline)) {              // image row `row` of g -> ring slot row % GRING
-            const bool ok = row < H;
-            const unsigned soff = ok ? (unsigned)row * (unsigned)W * gpitch : 0u;
-            const int slot = row % GRING;
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? rg1 : rg0, (lds_ptr_w)(smem + OFF_G + slot * GSLOT + pl * GPLANE + w * 1024), 16, ok ? gv : OOBW, soff, 0, 0);
-        };
+        auto dma_x = [&](int row) __attribute__((always_inline)) { dma_item(0, row, 0); dma_item(1, row, 0); dma_item(4, row, 0); dma_item(5, row, 0); };
+        auto dma_g = [&](int row) __attribute__((always_inline)) { dma_item(2, 0, row); dma_item(3, 0, row); };
         // ---- prologue of the strip: x rows -1 .. 2, g rows 0 .. 1 (the previous strip's last row must be done with the rings first)
         if (!first) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         first = false;
         dma_x(-1); dma_x(0); dma_x(1); dma_g(0); dma_x(2); dma_g(1);
         for (int y = 0; y < H; ++y) {
             // x rows <= y + 1 and g row y have landed once only the newest row's pieces are outstanding
-            if (w == 0) wait_vm_w<6>(); else wait_vm_w<4>();
+            if (!(WGX_ABL & 1)) { if (w == 0) wait_vm_w<6>(); else wait_vm_w<4>(); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            dma_x(y + 3);                                    // into the slot of row y - 2: free since the barrier above
-            dma_g(y + 2);
+            if (!(WGX_ABL & 8)) __builtin_amdgcn_s_barrier();
+            // (x row y + 3 goes into the slot of row y - 2 and g row y + 2 into that of row y - 1: free since the barrier above.  Their six DMA
+            // instructions are issued one behind each of the first six taps' MFMAs: issued in a block in front of them they cost the wave
+            // ~100 cycles each of matrix-pipe time: 17.4 against 13.1 ms of weight-gradient time per train step, tools/wgx_abl.sh)
             // ---- one k-step of 32 pixels (image row y of the strip), nine taps
             const unsigned gs_off = (unsigned)((y % GRING) * GSLOT);
             u32x2 gf[2][2][2];                               // [plane][block][i]
             auto rd = [&](u32x2& dst, unsigned addr, int imm) __attribute__((always_inline)) {
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
+                if (WGX_ABL & 2) asm volatile("; no read" : "=v"(dst) : "v"(addr), "n"(imm));
+                else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
             };
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
@@ -203,10 +212,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradX3Para
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
+                        if (WGX_ABL & 4) { asm volatile("" : "+v"(acc[t][a][b]) : "v"(ah[a]), "v"(al[a]), "v"(bh[b]), "v"(bl[b])); continue; }
                         acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bh[b], acc[t][a][b], 0, 0, 0);
                         acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bl[b], acc[t][a][b], 0, 0, 0);
                         acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bh[b], acc[t][a][b], 0, 0, 0);
                     }
+                if (t < 6) dma_item(t, y + 3, y + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
