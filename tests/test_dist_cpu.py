@@ -215,3 +215,52 @@ def test_bench_spawns_its_own_ranks():
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+VAL_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.path.join(%r, "highres-net_amd"))
+    sys.path.insert(0, %r)
+    import numpy as np, torch
+    from hrnet_hip import dist as hdist, validate
+    from oracle import hrnet_np as O
+    rank, local_rank, ws = hdist.init(backend="gloo")
+    # CPU stand-ins: a "fusion model" (bicubic x3 of the first view) and the numpy oracle's shift_cPSNR as the scorer; 7 imagesets of
+    # batch size 1 (train.py:281), dealt round-robin: rank 0 scores 4, rank 1 scores 3
+    class Toy(torch.nn.Module):
+        def forward(self, lrs, alphas):
+            return torch.nn.functional.interpolate(lrs[:, :1], scale_factor=3, mode="bicubic", align_corners=False)
+    def score(srs, hrs, maps):
+        return torch.tensor([O.shift_cpsnr(np.clip(s.numpy(), 0, 1), h.numpy(), m.numpy()) for s, h, m in zip(srs, hrs, maps)])
+    g = torch.Generator().manual_seed(3)
+    sets = []
+    for i in range(7):
+        lrs = torch.rand(1, 3, 16, 16, generator=g)
+        sets.append((lrs, torch.ones(1, 3), torch.rand(1, 48, 48, generator=g), (torch.rand(1, 48, 48, generator=g) > 0.1).float()))
+    model = Toy().train()
+    mine = [sets[i] for i in validate.shard_indices(len(sets), rank, ws)]
+    got = validate.sharded_val_score(model, mine, score_fn=score)
+    assert model.training                                   # the caller's mode is restored (train.py:196 / :160)
+    want = -float(np.mean([float(score(model(l, a)[:, 0], h, m)[0]) for l, a, h, m in sets]))
+    assert abs(got - want) <= 1e-12 * abs(want), (got, want)
+    hdist.barrier()
+    if rank == 0:
+        print("val score ok", got)
+    hdist.finalize()
+""") % (ROOT, ROOT)
+
+
+def test_two_rank_sharded_validation(tmp_path):
+    """train.py:196-215 sharded by imageset: every rank scores its own imagesets, one all-reduce of (sum, count); the
+    reduced val_score equals the single-process one.  CPU stand-ins for the model and for hrn_shift_cpsnr (the numpy oracle's)."""
+    script = tmp_path / "val_worker.py"
+    script.write_text(VAL_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    assert "val score ok" in outs[0][0]

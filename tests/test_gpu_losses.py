@@ -72,3 +72,26 @@ def test_hrnet_large_tiles_512():
         ref = m32(x, a)
     assert util.rel_err(y.cpu().numpy(), ref.cpu().numpy()) <= 4e-2
     assert util.psnr_db(y.cpu().numpy(), ref.cpu().numpy()) >= 42.0
+
+
+def test_sharded_val_score_single_rank_on_device():
+    """hrnet_hip.validate.sharded_val_score without a process group = the reference's validation loop (train.py:196-215) on device:
+    HRNet in eval mode, hrn_shift_cpsnr (clip to [0, 1], 7 x 7 offsets) per sample, minus the mean; the model's mode is restored."""
+    from hrnet_hip import validate
+    from oracle import synth
+    import util
+    m = util.hip_hrnet("fp32").train()
+    sets = []
+    for i in range(3):
+        lrs, alphas, hrs = synth.make_batch(40 + i, 1, 4, 32, 4)
+        maps = (np.random.Generator(np.random.PCG64(i)).random((1, 96, 96)) > 0.1).astype(np.float32)
+        sets.append((util.dev(lrs), util.dev(alphas), util.dev(hrs), util.dev(maps)))
+    got = validate.sharded_val_score(m, sets)
+    assert m.training
+    m.eval()
+    want = []
+    with torch.no_grad():
+        for lrs, alphas, hrs, maps in sets:
+            sr = m(lrs, alphas)[:, 0].clamp(0, 1).cpu().numpy()
+            want.append(O.shift_cpsnr(sr[0], hrs.cpu().numpy()[0], maps.cpu().numpy()[0]))
+    assert abs(got + float(np.mean(want))) <= 1e-4 * abs(float(np.mean(want))), (got, want)
