@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """tools/prof_collect.py TAG: turn gpurun_out/final/ (written by tools/prof_all.sh on the GPU box) into the committed evidence
-profiles/TAG_*: bench lines, the rocprofv3 kernel stats, the HBM traffic summary + profiles/r02_traffic.json (bytes per launch
+profiles/TAG_*: bench lines, the rocprofv3 kernel stats, the HBM traffic summary + profiles/<bench.TRAFFIC_JSON> (bytes per launch
 per kernel family, with a hash of the kernel sources so that bench.py never reports stale numbers), MFMA-busy / clock, stamps."""
 import collections, csv, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 O, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
 for src, dst in (("bench_steps20.json", "bench_steps20.json"), ("bench_train.json", "bench_train_steps5.json"), ("bench_steps5_kernel_stats.csv", "bench_steps5_kernel_stats.csv"),
-                 ("bench_steps5_under_rocprof.json", "bench_steps5_under_rocprof.json"), ("kbench_c5.txt", "kbench_c5.txt"), ("v6_stamps.txt", "v6_stamps.txt")):
+                 ("bench_steps5_under_rocprof.json", "bench_steps5_under_rocprof.json"), ("kbench_c5.txt", "kbench_c5.txt"), ("v6_stamps.txt", "v6_stamps.txt"),
+                 ("bench_x3_steps10.json", "bench_bf16x3_steps10.json"), ("bench_train_x3.json", "bench_train_bf16x3_steps5.json"),
+                 ("x3_kernel_stats.csv", "bf16x3_forward_kernel_stats.csv"), ("train_kernel_stats.csv", "train_step_kernel_stats.csv"),
+                 ("train_x3_kernel_stats.csv", "train_step_bf16x3_kernel_stats.csv"), ("kbench_x3.txt", "kbench_bf16x3.txt")):
     if os.path.exists(os.path.join(O, src)):
         shutil.copy(os.path.join(O, src), os.path.join(P, f"{tag}_{dst}"))
 
-FAMILY = [(r"conv3x3_v[67]_kernel<128, 2", "conv3x3_bf16_128x128+res"), (r"conv3x3_v[67]_kernel<128, 0", "conv3x3_bf16_128x128"),
-          (r"conv3x3_v[67]_kernel<64, 3", "conv3x3_bf16_128x64+res"), (r"conv3x3_v[67]_kernel<64, 0", "conv3x3_bf16_128x64"),
+FAMILY = [(r"conv3x3_v6_kernel<128, 128, 2, \w+, false>", "conv3x3_bf16_128x128+res"), (r"conv3x3_v6_kernel<128, 128, 0, \w+, false>", "conv3x3_bf16_128x128"),
+          (r"conv3x3_v6_kernel<128, 64, 3, \w+, false>", "conv3x3_bf16_128x64+res"), (r"conv3x3_v6_kernel<128, 64, 0, \w+, false>", "conv3x3_bf16_128x64"),
           (r"conv3x3_r64_kernel<false>", "conv3x3_bf16_64x64"), (r"conv3x3_r64_kernel<true>", "conv3x3_bf16_64x64+res"),
           (r"stem_mfma_kernel", "stem2x64_bf16"), (r"decoder_kernel", "decoder_bf16")]
 
@@ -56,7 +59,7 @@ json.dump({"_comment": "HBM bytes per average launch at the bench workload (B=32
                        "tools/kbench.py (tools/prof_all.sh), FETCH_SIZE doubled per MI355X_MICROARCH.md; raw means: profiles/" + tag + "_hbm_traffic_pmc.txt. "
                        "bench.py reports these as `traffic` only while kernel_source_hash matches the kernel sources in the tree.",
            "workload": {"batch": 32, "views": 32, "size": 128, "precision": "bf16"}, "kernel_source_hash": bench.kernel_source_hash(),
-           "bytes_per_launch": per_launch}, open(os.path.join(P, "r02_traffic.json"), "w"), indent=2)
+           "bytes_per_launch": per_launch}, open(os.path.join(P, bench.TRAFFIC_JSON), "w"), indent=2)
 
 # MFMA busy / clock
 dur = {}
