@@ -151,13 +151,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in0
 // for the lo half: D[co][px] = W hi + W lo.  One wave = one 32-pixel row segment x 64 channels = 6 MFMAs; fragments are
 // built in registers straight from the global loads (no LDS for operands); the result is transposed through a
 // wave-private LDS tile so that the NHWC stores are 16 B per lane, 8 lanes per 128-byte pixel line.
+// X3 (the bf16x3 mode): the WEIGHTS are split as well and the third term W lo x X hi joins the K axis - [18 hi | 18 hi | 18 lo | 10 zero]
+// against [18 hi | 18 lo | 18 hi | 10 zero] = 64 = four k-steps: fp32-grade products (~2^-16) -, and the fp32 result leaves as a pair of
+// bf16 planes (hi, lo), the lo plane out_lo bytes behind the hi plane.
+template <bool X3>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                         size_t img_stride0, int rep1, size_t img_stride1,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ slope, unsigned short* __restrict__ out,
-                                                        int M, int H, int W) {
+                                                        int M, int H, int W, size_t out_lo) {
     constexpr int SROW = 144;                                        // staged pixel row: 64 bf16 + 16 B pad
-    __shared__ __attribute__((aligned(16))) unsigned char stg_all[4 * 32 * SROW];
+    constexpr int NK = X3 ? 4 : 3;                                   // k-steps of 16
+    __shared__ __attribute__((aligned(16))) unsigned char stg_all[(X3 ? 2 : 1) * 4 * 32 * SROW];
     __shared__ __attribute__((aligned(16))) float bl[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -167,16 +172,17 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     unsigned char* stg = stg_all + wave * 32 * SROW;
 
     // A operand: lane (r, hh) holds W2[co = cb*32 + r][k = 16 s + 8 hh + j], W2[co][k] = w[co][k mod 18] for k < 36, else 0
-    bf16x8 wa[2][3];
+    bf16x8 wa[2][NK];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < NK; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * s + 8 * hh + j;
-                const float v = k < 36 ? w[(cb * 32 + r) * 18 + (k < 18 ? k : k - 18)] : 0.f;
-                wa[cb][s][j] = (__bf16)v;
+                const float v = k < (X3 ? 54 : 36) ? w[(cb * 32 + r) * 18 + (k % 18)] : 0.f;
+                const __bf16 h = (__bf16)v;
+                wa[cb][s][j] = (X3 && k >= 36) ? (__bf16)(v - (float)h) : h;      // third block: the weights' lo halves
             }
 
     const int segs_x = (W + 31) >> 5;
@@ -217,14 +223,16 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < NK; ++s) {
             bf16x8 bq;                                               // B[k = 16 s + 8 hh + j][col = this pixel]
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k0 = 16 * s + j, k1 = k0 + 8;              // the two candidates: hh = 0 / hh = 1
                 const __bf16 z = (__bf16)0.f;
-                const __bf16 c0 = k0 < 18 ? hi[k0] : (k0 < 36 ? lo[k0 - 18] : z);
-                const __bf16 c1 = k1 < 18 ? hi[k1] : (k1 < 36 ? lo[k1 - 18] : z);
+                auto pick = [&](int k) __attribute__((always_inline)) -> __bf16 {
+                    return k < 18 ? hi[k] : (k < 36 ? lo[k - 18] : ((X3 && k < 54) ? hi[k - 36] : z));
+                };
+                const __bf16 c0 = pick(k0), c1 = pick(k1);
                 bq[j] = hh ? c1 : c0;
             }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], bq, acc[0], 0, 0, 0);
@@ -242,10 +250,18 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                     const float t = acc[cb][4 * g + j] + bl[co + j];
                     v[j] = t >= 0.f ? t : a * t;
                 }
-                uint2 u;
-                u.x = pack2_bf16(v[0], v[1]);
-                u.y = pack2_bf16(v[2], v[3]);
-                *(uint2*)(stg + r * SROW + co * 2) = u;
+                if constexpr (X3) {
+                    uint2 uh, ul;
+                    split2_bf16(v[0], v[1], uh.x, ul.x);
+                    split2_bf16(v[2], v[3], uh.y, ul.y);
+                    *(uint2*)(stg + r * SROW + co * 2) = uh;
+                    *(uint2*)(stg + 4 * 32 * SROW + r * SROW + co * 2) = ul;
+                } else {
+                    uint2 u;
+                    u.x = pack2_bf16(v[0], v[1]);
+                    u.y = pack2_bf16(v[2], v[3]);
+                    *(uint2*)(stg + r * SROW + co * 2) = u;
+                }
             }
         // same wave reads back row-major: lane -> (pixel 8 i + lane/8, 16-byte part lane%8): 8 full lines per instruction
         unsigned short* orow = out + (((size_t)m * H + y) * W + sx * 32) * 64;
@@ -254,6 +270,10 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             const int px = 8 * i + (lane >> 3), part = lane & 7;
             const u32x4 v = *(const u32x4*)(stg + px * SROW + part * 16);
             if (sx * 32 + px < W) __builtin_nontemporal_store(v, (u32x4*)(orow + (size_t)px * 64 + part * 8));      // whole lines, read next from HBM
+            if constexpr (X3) {
+                const u32x4 vl = *(const u32x4*)(stg + 4 * 32 * SROW + px * SROW + part * 16);
+                if (sx * 32 + px < W) __builtin_nontemporal_store(vl, (u32x4*)((unsigned char*)(orow + (size_t)px * 64 + part * 8) + out_lo));
+            }
         }
     }
 }
@@ -322,8 +342,14 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
     if (dt == HRN_BF16 && sub == nullptr) {
         const size_t nseg = (size_t)M * H * ((W + 31) / 32);
         const int mblocks = (int)((nseg + 3) / 4 < 8192 ? (nseg + 3) / 4 : 8192);
-        hipLaunchKernelGGL(stem_mfma_kernel, dim3(mblocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, w, bias, slope,
-                           (unsigned short*)out, M, H, W);
+        hipLaunchKernelGGL(stem_mfma_kernel<false>, dim3(mblocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, w, bias, slope,
+                           (unsigned short*)out, M, H, W, (size_t)0);
+    } else if (dt == HRN_BF16X3 && sub == nullptr) {
+        HRN_CHECK(out_lo != 0, -2, "stem bf16x3: lo-plane offset missing");
+        const size_t nseg = (size_t)M * H * ((W + 31) / 32);
+        const int mblocks = (int)((nseg + 3) / 4 < 8192 ? (nseg + 3) / 4 : 8192);
+        hipLaunchKernelGGL(stem_mfma_kernel<true>, dim3(mblocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, w, bias, slope,
+                           (unsigned short*)out, M, H, W, out_lo);
     } else if (dt == HRN_BF16X3) {
         HRN_CHECK(out_lo != 0, -2, "stem bf16x3: lo-plane offset missing");
         hipLaunchKernelGGL(stem_kernel<HRN_BF16X3>, dim3(blocks), dim3(256), 0, stream, in0, in1, img_stride0, rep1, img_stride1, sub, w, bias, slope, out, M, H, W,
