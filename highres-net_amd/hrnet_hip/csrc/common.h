@@ -11,8 +11,6 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // 16-byte staging unit (native vector: stays in VGPRs)
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;   // 8 bytes = 4 bf16

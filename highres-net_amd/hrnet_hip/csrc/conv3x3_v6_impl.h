@@ -41,9 +41,6 @@ constexpr int HW6 = T6_W + 2;                              // halo width 34
 constexpr int NPIX6 = (T6_H + 2) * HW6;                    // 612 halo pixels
 constexpr int N_IN6 = (NPIX6 * 64 + 1023) / 1024;          // 39 DMA pieces of 1 KB per 32-channel halo chunk
 constexpr int IN_BYTES6 = N_IN6 * 1024;                    // 39,936
-#ifndef V6_EPI
-#define V6_EPI 1                                            // 1: packed-math epilogue (pk_mul + dot2c residual), 0: the scalar one (A/B builds)
-#endif
 constexpr unsigned OOB6 = 0x80000000u;                     // byte offset no descriptor of this kernel covers
 
 template <int COUT, bool X3 = false> struct G6 {
@@ -567,49 +564,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                     }
                     __builtin_amdgcn_sched_barrier(0);               // (hipcc would otherwise start all four rounds' loads here and spill them)
                     {
-#if V6_EPI
-                        // bf16 (1, 0) and (0, 1) from registers: as an immediate the first becomes the inline constant "1.0", which the
-                        // instruction does not read as a packed bf16 (measured: wrong sums)
-                        unsigned one_lo = 0x00003f80u, one_hi = 0x3f800000u;
-                        asm volatile("" : "+s"(one_lo), "+s"(one_hi));
-#endif
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int gy = y0 + 2 * w + (r >> 1);
-#if V6_EPI
-                            // The epilogue is VALU-issue bound (two waves per SIMD, ~5 instructions per accumulator).  Packed fp32 for what
-                            // pairs up in registers - an accumulator quad is four pixels of one cout: slope * x as two v_pk_mul_f32 -, and
-                            // the residual is added WITHOUT being unpacked: v_dot2c_f32_bf16 (r.lo, r.hi) . (1, 0) + y = y + r.lo, exact.
-                            f32x4 yv[NCB];
-#pragma unroll
-                            for (int cb = 0; cb < NCB; ++cb) {
-                                const f32x4 x = acc[cb][r];
-                                const f32x2 s01 = f32x2{x[0], x[1]} * act_slope, s23 = f32x2{x[2], x[3]} * act_slope;
-                                f32x4 y;
-                                y[0] = __builtin_amdgcn_fmed3f(x[0], s01[0], act_pick);
-                                y[1] = __builtin_amdgcn_fmed3f(x[1], s01[1], act_pick);
-                                y[2] = __builtin_amdgcn_fmed3f(x[2], s23[0], act_pick);
-                                y[3] = __builtin_amdgcn_fmed3f(x[3], s23[1], act_pick);
-                                if (RESM == 3) {
-                                    const f32x2 a01 = f32x2{y[0], y[1]} * res_alpha, a23 = f32x2{y[2], y[3]} * res_alpha;
-                                    y = f32x4{a01[0], a01[1], a23[0], a23[1]};
-                                }
-                                if (RES) {
-                                    const bf16x2 pick = __builtin_bit_cast(bf16x2, (cb & 1) ? one_hi : one_lo);
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j)
-                                        y[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, (unsigned)rq[r][j][cb >> 1]), pick, y[j], false);
-                                }
-                                yv[cb] = y;
-                            }
-#endif
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 lane_row_t o;
-#if V6_EPI
-#pragma unroll
-                                for (int i = 0; i < NCB / 2; ++i) o[i] = pack2_bf16(yv[2 * i][j], yv[2 * i + 1][j]);
-#else
                                 const lane_row_t rv = rq[r][j];
 #pragma unroll
                                 for (int i = 0; i < NCB / 2; ++i) {
@@ -623,7 +583,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_v6_kernel(const ConvParams p) 
                                     }
                                     o[i] = pack2_bf16(xa, xb);
                                 }
-#endif
                                 const int gx = x0 + 16 * (r & 1) + 4 * qe + j;
                                 // a pixel outside the image gets an offset the descriptor's range check drops: no branch around the store
                                 const unsigned voff = (unsigned)((gy * W + gx) * ROW + c15e * LB) | ((unsigned)(W - 1 - gx) & OOB6) | (gy < H ? 0u : OOB6);
