@@ -134,18 +134,20 @@ __global__ __launch_bounds__(256) void prelu_bwd_bias_kernel(const void* __restr
     if (threadIdx.x == 0) slopepart[blockIdx.x] = sred[0];
 }
 
-// out[c] += sum over blocks of partial[b][c]: one block per 32 channels, 8 block-phases per channel, fixed order
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-    __shared__ double red[8][32];
+// out[c] += sum over blocks of partial[b][c]: one block per 32 channels, 32 block-phases per channel (the loop is a chain of loads: its
+// length, not the bytes, is what a finish costs), fixed order
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+    __shared__ double red[32][32];
     const int cl = threadIdx.x & 31, ph = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int b = ph; b < nblk; b += 8) s += partial[(size_t)b * C + c];
+#pragma unroll 4
+    for (int b = ph; b < nblk; b += 32) s += partial[(size_t)b * C + c];
     red[ph][cl] = s;
     __syncthreads();
     if (ph == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        for (int k = 0; k < 32; ++k) t += red[k][cl];
         out[c] += (float)t;
     }
 }
@@ -324,18 +326,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
 }
 
 // dW[co][ci][tap] (OIHW, full cin/cout) += sum over workgroups of partial[blk][tap][co_l][ci_l]
-__global__ void wgrad_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dw, int cin, int co_chunk,
+__global__ __launch_bounds__(1024) void wgrad_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dw, int cin, int co_chunk,
                                     int ci_chunk) {
-    // block = 64 consecutive elements x 4 workgroup phases (more loads in flight than one thread per element), fixed order
-    __shared__ double red[4][64];
+    // block = 64 consecutive elements x 16 workgroup phases (more loads in flight than one thread per element), fixed order
+    __shared__ double red[16][64];
     const int el = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + el;                       // over 9 * 64 * 64
     double s = 0.0;
-    for (int b = ph; b < nblk; b += 4) s += (double)partial[(size_t)b * 9 * 4096 + idx];
+#pragma unroll 4
+    for (int b = ph; b < nblk; b += 16) s += (double)partial[(size_t)b * 9 * 4096 + idx];
     red[ph][el] = s;
     __syncthreads();
     if (ph != 0) return;
-    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
     const int tap = idx / 4096, co_l = (idx >> 6) & 63, ci_l = idx & 63;
     const int co = co_chunk * 64 + co_l, ci = ci_chunk * 64 + ci_l;
     dw[((size_t)co * cin + ci) * 9 + tap] += (float)s;
@@ -401,17 +406,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 }
 // dw[idx] += sum over rows of partial[row][idx], idx over 64 * 18 (dw layout [co][c2][3][3] = co*18 + c*9 + tap): 16 outputs x 16 row
 // phases per workgroup, fixed order
-__global__ __launch_bounds__(256) void stem_wgrad_finish_kernel(const float* __restrict__ partial, int nrows, float* __restrict__ dw) {
-    __shared__ double red[16][16];
+__global__ __launch_bounds__(1024) void stem_wgrad_finish_kernel(const float* __restrict__ partial, int nrows, float* __restrict__ dw) {
+    __shared__ double red[64][16];
     const int o = threadIdx.x & 15, ph = threadIdx.x >> 4, idx = blockIdx.x * 16 + o;
     double s = 0.0;
-    for (int b = ph; b < nrows; b += 16) s += (double)partial[(size_t)b * 64 * 18 + idx];
+#pragma unroll 4
+    for (int b = ph; b < nrows; b += 64) s += (double)partial[(size_t)b * 64 * 18 + idx];
     red[ph][o] = s;
     __syncthreads();
     if (ph == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][o];
+        for (int k = 0; k < 64; ++k) t += red[k][o];
         dw[idx] += (float)t;
     }
 }
@@ -502,7 +508,7 @@ int hrn_launch_prelu_bwd_bias(const float* dy, const float* y, const float* xpre
     if (C == 64) { if (x3) HRN_PB(64, true); else HRN_PB(64, false); }
     else { if (x3) HRN_PB(128, true); else HRN_PB(128, false); }
 #undef HRN_PB
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(256), 0, s, colpart, blocks, C, db);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(1024), 0, s, colpart, blocks, C, db);
     hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, s, slopepart, blocks, dslope);
     HRN_LAUNCH_CHECK();
     return 0;
@@ -517,7 +523,7 @@ int hrn_launch_colsum(const float* g, size_t rows, int C, float* db, void* scrat
     if (C == 64) { if (x3) HRN_CS(64, true); else HRN_CS(64, false); }
     else { if (x3) HRN_CS(128, true); else HRN_CS(128, false); }
 #undef HRN_CS
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(256), 0, s, partial, blocks, C, db);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(C / 32), dim3(1024), 0, s, partial, blocks, C, db);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -530,7 +536,7 @@ int hrn_launch_dgrad_weights(const float* w, float* wt, int cin, int cout, hipSt
 }
 
 int hrn_launch_wgrad_finish(const float* partial, int nblk, float* dw, int cin, int co_chunk, int ci_chunk, hipStream_t s) {
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(9 * 4096 / 64), dim3(256), 0, s, partial, nblk, dw, cin, co_chunk, ci_chunk);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(9 * 4096 / 64), dim3(1024), 0, s, partial, nblk, dw, cin, co_chunk, ci_chunk);
     HRN_LAUNCH_CHECK();
     return 0;
 }
@@ -551,7 +557,7 @@ int hrn_launch_conv_wgrad(const float* x, const float* stack, int in_pair, int p
         for (int ic = 0; ic < cin / 64; ++ic) {
             p.co_chunk = cc; p.ci_chunk = ic;
             hipLaunchKernelGGL(conv_wgrad_kernel, dim3(grid), dim3(256), WG_LDS, s, p);
-            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(9 * 4096 / 64), dim3(256), 0, s, (const float*)scratch, grid, dw, cin, cc, ic);
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(9 * 4096 / 64), dim3(1024), 0, s, (const float*)scratch, grid, dw, cin, cc, ic);
         }
     HRN_LAUNCH_CHECK();
     return 0;
@@ -569,7 +575,7 @@ int hrn_launch_stem_wgrad_sub(const float* in0, size_t stride0, const float* in1
     if (tiles < grid) grid = (int)tiles;
     if (dt == HRN_BF16X3) hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, sub, (const void*)g, M, H, W, (float*)scratch);
     else hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(256), 0, s, in0, stride0, in1, rep1, stride1, sub, (const void*)g, M, H, W, (float*)scratch);
-    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3(64 * 18 / 16), dim3(256), 0, s, (const float*)scratch, grid * 4, dw);
+    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3(64 * 18 / 16), dim3(1024), 0, s, (const float*)scratch, grid * 4, dw);
     HRN_LAUNCH_CHECK();
     return 0;
 }

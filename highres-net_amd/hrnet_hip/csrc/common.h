@@ -153,6 +153,22 @@ template <bool X3> __device__ __forceinline__ float act_ld1(const void* p, size_
     else return ((const float*)p)[i];
 }
 
+// (s, ss) = sum over k < nblk of partial[(k * C + c) * 2 + {0, 1}] for channel c = threadIdx.x % C, by a block of 1024 threads = C channels
+// x (1024 / C) phases (C = 64 or 128), fixed order; valid in the threads with threadIdx.x < C.  A finish kernel is a chain of dependent
+// loads: one thread per channel took 65 us for 256 slabs, this takes ~5.
+__device__ __forceinline__ void block_pair_sum(const double* __restrict__ partial, int nblk, int C, double& s, double& ss) {
+    __shared__ double red_ps[2][1024];
+    const int c = (int)threadIdx.x % C, ph = (int)threadIdx.x / C, nph = (int)blockDim.x / C;
+    double a = 0.0, b = 0.0;
+#pragma unroll 4
+    for (int k = ph; k < nblk; k += nph) { a += partial[((size_t)k * C + c) * 2]; b += partial[((size_t)k * C + c) * 2 + 1]; }
+    red_ps[0][threadIdx.x] = a; red_ps[1][threadIdx.x] = b;
+    __syncthreads();
+    if (ph == 0)
+        for (int k = 1; k < nph; ++k) { a += red_ps[0][k * C + c]; b += red_ps[1][k * C + c]; }
+    s = a; ss = b;
+}
+
 static inline size_t hrn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // bytes per element of an activation / weight tensor (bf16x3: both planes together)
 static inline int hrn_esize(int dt) { return dt == HRN_BF16 ? 2 : 4; }

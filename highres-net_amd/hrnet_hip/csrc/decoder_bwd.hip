@@ -102,22 +102,38 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(const float* __rest
     }
 }
 
-__global__ void decoder_bwd_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dwd, float* __restrict__ dbd,
-                                          float* __restrict__ dad, float* __restrict__ dwf, float* __restrict__ dbf) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= DB_DW + 128 + 2) return;
+// blocks 0 .. (DB_DW + 128) / 64 - 1: 64 consecutive elements x 16 slab phases; the last two blocks: the two scalars (slope, final
+// bias), whose 64 per-lane terms per slab are summed by 64 x 16 threads as well.  Fixed order throughout.
+__global__ __launch_bounds__(1024) void decoder_bwd_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dwd,
+                                                                  float* __restrict__ dbd, float* __restrict__ dad, float* __restrict__ dwf,
+                                                                  float* __restrict__ dbf) {
+    __shared__ double red[16][64];
+    const int el = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    constexpr int NEB = (DB_DW + 128) / 64;
+    const bool scalar = (int)blockIdx.x >= NEB;
+    const int idx = scalar ? (blockIdx.x == NEB ? DB_DW + 128 : DB_DW + 192) + el : blockIdx.x * 64 + el;
     double s = 0.0;
-    if (idx < DB_DW + 128) {
-        for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * DB_SLAB + idx];
+#pragma unroll 4
+    for (int b = ph; b < nblk; b += 16) s += (double)partial[(size_t)b * DB_SLAB + idx];
+    red[ph][el] = s;
+    __syncthreads();
+    if (ph != 0) return;
+    s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
+    if (!scalar) {
         if (idx < DB_DW) dwd[idx] += (float)s;
         else if (idx < DB_DW + 64) dbd[idx - DB_DW] += (float)s;
         else dwf[idx - DB_DW - 64] += (float)s;
-    } else {
-        const int base = idx == DB_DW + 128 ? DB_DW + 128 : DB_DW + 192;
-        for (int b = 0; b < nblk; ++b)
-            for (int l = 0; l < 64; ++l) s += (double)partial[(size_t)b * DB_SLAB + base + l];
-        if (idx == DB_DW + 128) dad[0] += (float)s;
-        else dbf[0] += (float)s;
+        return;
+    }
+    // the 64 lane terms of a scalar: one wave, fixed order
+    red[0][el] = s;                                         // (one wave is left: its LDS accesses are ordered)
+    if (el == 0) {
+        double t = 0.0;
+        for (int l = 0; l < 64; ++l) t += red[0][l];
+        if ((int)blockIdx.x == NEB) dad[0] += (float)t;
+        else dbf[0] += (float)t;
     }
 }
 
@@ -132,7 +148,8 @@ int hrn_launch_decoder_bwd(const float* fused, const float* d_sr, const float* w
     int grid = num_cus;
     if (P < grid) grid = (int)P;
     hipLaunchKernelGGL(decoder_bwd_kernel, dim3(grid), dim3(256), 0, s, fused, d_sr, wd, bd, ad, wf, d_fused, (float*)scratch, N, H, W);
-    hipLaunchKernelGGL(decoder_bwd_finish_kernel, dim3((DB_DW + 130 + 255) / 256), dim3(256), 0, s, (const float*)scratch, grid, dwd, dbd,
+    static_assert((DB_DW + 128) % 64 == 0, "decoder_bwd_finish: 64 elements per block");
+    hipLaunchKernelGGL(decoder_bwd_finish_kernel, dim3((DB_DW + 128) / 64 + 2), dim3(1024), 0, s, (const float*)scratch, grid, dwd, dbd,
                        dad, dwf, dbf);
     HRN_LAUNCH_CHECK();
     return 0;

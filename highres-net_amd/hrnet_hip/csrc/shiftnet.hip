@@ -29,14 +29,14 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 // stage 2: mean / biased var -> scale, shift; running stats (momentum, unbiased var) updated in place when given
-__global__ void bn_finish_kernel(const double* __restrict__ partial, int nblk, size_t npix, int C,
+__global__ __launch_bounds__(1024) void bn_finish_kernel(const double* __restrict__ partial, int nblk, size_t npix, int C,
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                  float* __restrict__ scale, float* __restrict__ shift,
                                  float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = threadIdx.x;
+    double s, ss;
+    block_pair_sum(partial, nblk, C, s, ss);
     if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * C + c) * 2]; ss += partial[((size_t)b * C + c) * 2 + 1]; }
     const double n = (double)npix;
     const double mean = s / n;
     double var = ss / n - mean * mean;
@@ -219,7 +219,7 @@ int hrn_launch_bn_stats(const float* x, size_t npix, int C, const float* gamma, 
     HrnProfScope prof("bn_stats", 0.0, (double)npix * C * 4, stream);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(partial_blocks), dim3(256), 0, stream, x, npix, C, partial);
     HRN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(128), 0, stream, partial, partial_blocks, npix, C, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(1024), 0, stream, partial, partial_blocks, npix, C, gamma, beta, eps,
                        scale, shift, running_mean, running_var, momentum);
     HRN_LAUNCH_CHECK();
     return 0;

@@ -24,12 +24,12 @@ namespace {
 constexpr int FCK = 32768;
 
 // ------------------------------------------------------------------------------------------------ BatchNorm (train) helpers
-__global__ void bn_save_stats_kernel(const double* __restrict__ partial, int nblk, size_t npix, int C, float eps, float* __restrict__ mean,
+__global__ __launch_bounds__(1024) void bn_save_stats_kernel(const double* __restrict__ partial, int nblk, size_t npix, int C, float eps, float* __restrict__ mean,
                                      float* __restrict__ invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = threadIdx.x;
+    double s, ss;
+    block_pair_sum(partial, nblk, C, s, ss);
     if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * C + c) * 2]; ss += partial[((size_t)b * C + c) * 2 + 1]; }
     const double n = (double)npix, m = s / n;
     double var = ss / n - m * m;
     var = var < 0.0 ? 0.0 : var;
@@ -103,12 +103,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 // sums[c] = (sum d v, sum d v xhat);  d beta += , d gamma +=
-__global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int nblk, int C, double* __restrict__ sums,
+__global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const double* __restrict__ partial, int nblk, int C, double* __restrict__ sums,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = threadIdx.x;
+    double a, b;
+    block_pair_sum(partial, nblk, C, a, b);
     if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) { a += partial[((size_t)k * C + c) * 2]; b += partial[((size_t)k * C + c) * 2 + 1]; }
     sums[c * 2] = a; sums[c * 2 + 1] = b;
     dbeta[c] += (float)a;
     dgamma[c] += (float)b;
@@ -344,7 +344,7 @@ int hrn_shiftnet_forward_train(const void* packed, const hrn_shiftnet_params* P,
         const size_t npix = (size_t)B * h * h;
         if ((rc = hrn_launch_bn_stats(xp, npix, C, P->bn_g[i], P->bn_b[i], 1e-5f, st + 256, st + 384, P->bn_rm[i], P->bn_rv[i], momentum,
                                       partial, SN_PARTIAL_BLOCKS, s))) return rc;
-        hipLaunchKernelGGL(bn_save_stats_kernel, dim3(1), dim3(128), 0, s, (const double*)partial, SN_PARTIAL_BLOCKS, npix, C, 1e-5f, st, st + 128);
+        hipLaunchKernelGGL(bn_save_stats_kernel, dim3(1), dim3(1024), 0, s, (const double*)partial, SN_PARTIAL_BLOCKS, npix, C, 1e-5f, st, st + 128);
         HRN_LAUNCH_CHECK();
         if ((rc = hrn_launch_bn_act_pool(xp, st + 256, st + 384, yp, B, h, h, C, SN_POOL[i], s))) return rc;
     }
@@ -396,7 +396,7 @@ int hrn_shiftnet_backward(const hrn_shiftnet_params* P, const float* x, int B, c
         const size_t npix = (size_t)B * h * h;
         if (SN_POOL[i]) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(SN_PARTIAL_BLOCKS), dim3(256), 0, s, xp, (const float*)cur, st, B, h, h, C, partial);
         else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(SN_PARTIAL_BLOCKS), dim3(256), 0, s, xp, (const float*)cur, st, B, h, h, C, partial);
-        hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(1), dim3(128), 0, s, (const double*)partial, SN_PARTIAL_BLOCKS, C, sums, mut(G->bn_g[i]), mut(G->bn_b[i]));
+        hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(1), dim3(1024), 0, s, (const double*)partial, SN_PARTIAL_BLOCKS, C, sums, mut(G->bn_g[i]), mut(G->bn_b[i]));
         const int eg = ew_grid(npix * C / 4 / (SN_POOL[i] ? 4 : 1));
         if (SN_POOL[i]) hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(eg), dim3(256), 0, s, xp, (const float*)cur, st, P->bn_g[i], (const double*)sums, oth, B, h, h, C);
         else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(eg), dim3(256), 0, s, xp, (const float*)cur, st, P->bn_g[i], (const double*)sums, oth, B, h, h, C);
