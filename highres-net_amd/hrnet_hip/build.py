@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhrnet_hip.so")
-SOURCES = ["api.hip", "prof.hip", "conv3x3.hip", "conv3x3_r64.hip", "conv3x3_v6.hip", "conv3x3_v6x3.hip", "conv3x3_v11.hip", "backward.hip", "wgrad_x3.hip", "decoder_bwd.hip", "train.hip", "stem.hip", "decoder.hip", "lanczos.hip", "lanczos_bwd.hip", "shiftnet.hip", "shiftnet_bwd.hip", "adam.hip", "losses.hip"]
+SOURCES = ["api.hip", "prof.hip", "conv3x3.hip", "conv3x3_r64.hip", "conv3x3_v6.hip", "conv3x3_v6x3.hip", "backward.hip", "wgrad_x3.hip", "decoder_bwd.hip", "train.hip", "stem.hip", "decoder.hip", "lanczos.hip", "lanczos_bwd.hip", "shiftnet.hip", "shiftnet_bwd.hip", "adam.hip", "losses.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -44,10 +44,6 @@ int hrn_launch_conv3x3_r64(const ConvParams& p, hipStream_t stream);
 // from the accumulators in whole pixel rows (conv3x3_v6.hip); -100 = not applicable.
 int hrn_launch_conv3x3_v6(int cout, const ConvParams& p, hipStream_t stream);
 
-// The same three layers with the epilogue interleaved into each wave's own MFMA stream: the stages either side of a tile boundary run
-// pixel row by pixel row, so that half of the accumulators are final half a stage early (conv3x3_v11.hip); same applicability as v6.
-int hrn_launch_conv3x3_v11(int cout, const ConvParams& p, hipStream_t stream);
-
 // bf16x3 (split-bf16: hi/lo planes, three MFMAs per product) on the conv3x3_v6 skeleton: (cin, cout) = (64, 64) with res_mode 0 | 1,
 // (128, 128) with 0 | 2 (+ pair-gather input), (128, 64) with 0 | 3 (conv3x3_v6x3.hip).  No other kernel implements this dtype.
 int hrn_launch_conv3x3_v6x3(int cin, int cout, const ConvParams& p, hipStream_t stream);

@@ -390,8 +390,6 @@ int hrn_launch_conv3x3(int dt, int cin, int cout, const ConvParams& p, hipStream
         static const int r64 = [] { const char* e = getenv("HRN_CONV_R64"); return e ? atoi(e) : 1; }();
         static const int v6 = [] { const char* e = getenv("HRN_CONV_V6"); return e ? atoi(e) : 1; }();
         if (cin == 64 && cout == 64 && r64) { const int rc = hrn_launch_conv3x3_r64(p, stream); if (rc != -100) return rc; }
-        static const int v11 = [] { const char* e = getenv("HRN_CONV_V11"); return e ? atoi(e) : 0; }();
-        if (cin == 128 && v6 && v11) { const int rc = hrn_launch_conv3x3_v11(cout, p, stream); if (rc != -100) return rc; }
         if (cin == 128 && v6) { const int rc = hrn_launch_conv3x3_v6(cout, p, stream); if (rc != -100) return rc; }
     }
 #define HRN_CONV_CASE(DT_, CI_, CO_) if (dt == DT_ && cin == CI_ && cout == CO_) return launch<DT_, CI_, CO_>(p, stream);
