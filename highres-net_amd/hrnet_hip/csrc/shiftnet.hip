@@ -105,65 +105,72 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* __restric
 // row is consumed in whole 128-byte lines) and of its sample row r: k = ks + 16 hh + t feeds MFMA t of the step on both sides - the
 // order in which a product's k is visited is free.  Weights are read once: non-temporal; xr (L2 resident) by plain loads.  The
 // slices' partial sums land in `partial` [FC_SPLIT][32][1024] and fc1_finish_kernel adds them in slice order: bit-reproducible.
-#ifndef FC_SPLIT_N
-#define FC_SPLIT_N 64
-#endif
-#ifndef FC_NBW
-#define FC_NBW 2          // neuron blocks of 32 per wave (they share the wave's xr fragments)
-#endif
-#ifndef FC_DEPTH
-#define FC_DEPTH 2        // super-steps of loads in flight
-#endif
-constexpr int FC_K = 32768, FC_SPLIT = FC_SPLIT_N, FC_KS = FC_K / FC_SPLIT;
+// fc1 (ShiftNet.py:44,69-72): y[b][j] = sum_k x[b][k] w[j][k], K = 32,768, 1,024 neurons, <= 32 samples per pass: 134 MB of weights read
+// once, nothing else of size: an HBM-bound kernel.  Round 2's version loaded the MFMA operand layout straight from global memory - lane r
+// = weight row r, 16 bytes per lane: 64 scattered 16-byte requests per instruction - and stayed at 1.8 TB/s whatever its depth.  Here the
+// weights (and the activations) go through LDS by DMA in the order they lie in memory: one 1 KB instruction = 256 consecutive k of ONE
+// row, 64 rows (32 neurons + 32 samples) per stage, the next stage in flight while this one is multiplied: 64 KB per CU on the wire,
+// every request a run of whole lines.  LDS rows are 1,040 bytes apart (16 rows = 64 distinct banks for the operand reads).
+// One workgroup = 32 neurons x one K slice of 4,096 (16 stages); wave v multiplies k = 64 v .. 64 v + 63 of a stage on the exact-fp32
+// MFMA (v_mfma_f32_32x32x2_f32: lane (r, hh) supplies x[sample r][k + hh], w[neuron r][k + hh]) and writes its own partial slab:
+// 8 slices x 4 waves = 32 slabs, summed in fixed order by fc1_finish_kernel.  Workgroup id = slice + 8 x neuron block: the workgroups of
+// a slice share an XCD, whose L2 then holds that slice of the activations (512 KB) for all 32 of them.
+constexpr int FC_K = 32768;
+constexpr int FC_SLICES = 8, FC_KS = FC_K / FC_SLICES;       // K slices, k per slice
+constexpr int FC_KST = 256, FC_NST = FC_KS / FC_KST;          // k per stage (1 KB of a row), stages per slice
+constexpr int FC_SPLIT = FC_SLICES * 4;                       // partial slabs: one per (slice, wave)
+constexpr int FC_PITCH = 1024 + 16;                           // LDS row pitch in bytes
+constexpr int FC_STAGE_BYTES = 64 * FC_PITCH;                 // 32 weight rows, then 32 activation rows
+constexpr int FC_LDS_BYTES = 2 * FC_STAGE_BYTES;              // double buffer: 133,120 B
+typedef __attribute__((address_space(3))) void* fc_lds_ptr;
 __global__ __launch_bounds__(256) void fc1_mfma_kernel(const float* __restrict__ xr, const float* __restrict__ w, float* __restrict__ partial, int B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    constexpr int NBG = 32 / FC_NBW;                                     // neuron groups
-    const int nb = wid % NBG, sl = wid / NBG;
-    const float* wp = w + (size_t)(nb * 32 * FC_NBW + r) * FC_K + sl * FC_KS + 16 * hh;
-    const float* xp = xr + (size_t)(r < B ? r : B - 1) * FC_K + sl * FC_KS + 16 * hh;      // rows beyond the batch: any valid row, never stored
-    f32x16 acc[FC_NBW];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sl = blockIdx.x & (FC_SLICES - 1), nb = blockIdx.x / FC_SLICES;
+    // rows of a stage: 0..31 = neurons nb*32 + row, 32..63 = samples row - 32 (beyond the batch: the last valid sample, never stored).
+    // Wave v fetches rows v, v + 4, ...: lane l takes bytes 16 l .. 16 l + 15 of the row's 1 KB
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(w + (size_t)nb * 32 * FC_K), 0, (int)(32u * FC_K * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xr, 0, (int)((unsigned)B * FC_K * 4u), 0x00020000);
+    auto fetch = [&](int buf, int st) __attribute__((always_inline)) {
+        const unsigned kofs = (unsigned)((sl * FC_KS + st * FC_KST) * 4);
 #pragma unroll
-    for (int q = 0; q < FC_NBW; ++q)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
-    f32x4 wv[FC_DEPTH][FC_NBW][4], xv[FC_DEPTH][4];
-    auto fetch = [&](int buf, int step) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int q = 0; q < FC_NBW; ++q) wv[buf][q][i] = __builtin_nontemporal_load((const f32x4*)(wp + (size_t)q * 32 * FC_K + step * 32 + 4 * i));
-            xv[buf][i] = *(const f32x4*)(xp + step * 32 + 4 * i);
+        for (int i = 0; i < 16; ++i) {
+            const int row = wv + 4 * i;                                   // i < 8: weight rows, i >= 8: activation rows (wave-uniform)
+            unsigned char* dst = fc_smem + buf * FC_STAGE_BYTES + row * FC_PITCH;
+            if (i < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (fc_lds_ptr)dst, 16, (unsigned)(lane * 16), kofs + (unsigned)row * (FC_K * 4u), 0, 2);
+            else {
+                const int smp = row - 32 < B ? row - 32 : B - 1;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (fc_lds_ptr)dst, 16, (unsigned)(lane * 16), kofs + (unsigned)smp * (FC_K * 4u), 0, 0);
+            }
         }
     };
-    auto multiply = [&](int buf) __attribute__((always_inline)) {
+    f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    fetch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int st = 0; st < FC_NST; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < FC_NST) fetch(buf ^ 1, st + 1);
+        const unsigned char* wrow = fc_smem + buf * FC_STAGE_BYTES + r * FC_PITCH + (64 * wv + 4 * hh) * 4;
+        const unsigned char* xrow = wrow + 32 * FC_PITCH;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int sb = 0; sb < 8; ++sb) {
+            const f32x4 wq = *(const f32x4*)(wrow + sb * 32), xq = *(const f32x4*)(xrow + sb * 32);
 #pragma unroll
-                for (int q = 0; q < FC_NBW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[buf][i][e], wv[buf][q][i][e], acc[q], 0, 0, 0);
-    };
-    constexpr int NS = FC_KS / 32;                                       // super-steps of the slice
-    static_assert(NS % FC_DEPTH == 0, "slice length");
-#pragma unroll
-    for (int d = 0; d < FC_DEPTH; ++d) fetch(d, d);
-    for (int st = 0; st < NS; st += FC_DEPTH) {
-#pragma unroll
-        for (int d = 0; d < FC_DEPTH; ++d) {
-            multiply(d);
-            if (st + FC_DEPTH + d < NS) fetch(d, st + FC_DEPTH + d);
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xq[e], wq[e], acc, 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next stage has landed (this wave's share; the barrier covers the others')
+        __syncthreads();
     }
     // element 4 g + e of lane (r, hh) = sample 8 g + 4 hh + e, neuron r: 32 lanes write 128 contiguous bytes
+    float* pp = partial + ((size_t)(sl * 4 + wv) * 32) * 1024 + nb * 32 + r;
 #pragma unroll
-    for (int q = 0; q < FC_NBW; ++q) {
-        float* pp = partial + ((size_t)sl * 32) * 1024 + (nb * FC_NBW + q) * 32 + r;
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pp[(size_t)(8 * g + 4 * hh + e) * 1024] = acc[q][4 * g + e];
-    }
+        for (int e = 0; e < 4; ++e) pp[(size_t)(8 * g + 4 * hh + e) * 1024] = acc[4 * g + e];
 }
 __global__ __launch_bounds__(256) void fc1_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y, int B) {
     const int idx = blockIdx.x * 256 + threadIdx.x;                      // b * 1024 + j
@@ -260,7 +267,8 @@ int hrn_launch_fc1(const float* xr, const float* w, const float* b, float* y, in
         const int nb = B - b0 < 32 ? B - b0 : 32;
         {
             HrnProfScope prof("fc1", 2.0 * nb * 1024 * 32768, 1024.0 * 32768 * 4 + (double)nb * 32768 * 4, stream);
-            hipLaunchKernelGGL(fc1_mfma_kernel, dim3(32 / FC_NBW * FC_SPLIT / 4), dim3(256), 0, stream, xr + (size_t)b0 * FC_K, w, partial, nb);
+            { const int rc_lds = hrn_allow_lds((const void*)fc1_mfma_kernel, FC_LDS_BYTES); if (rc_lds) return rc_lds; }
+            hipLaunchKernelGGL(fc1_mfma_kernel, dim3(32 * FC_SLICES), dim3(256), FC_LDS_BYTES, stream, xr + (size_t)b0 * FC_K, w, partial, nb);
         }
         hipLaunchKernelGGL(fc1_finish_kernel, dim3((nb * 1024 + 255) / 256), dim3(256), 0, stream, (const float*)partial, b, y + (size_t)b0 * 1024, nb);
         HRN_LAUNCH_CHECK();
