@@ -238,30 +238,65 @@ __global__ __launch_bounds__(256) void fc1_bwd_w_kernel(const float* __restrict_
         *o += s;
     }
 }
-// dxr[b][k] = sum_j dz1[b][j] * w1[j][k]        grid (FCK / 64) workgroups of ONE wave (512 of them: every CU streams its share of the
-// 134 MB weight read; 128 workgroups of 256 threads left half the chip idle), B <= 32 per launch
-__global__ __launch_bounds__(64) void fc1_bwd_x_kernel(const float* __restrict__ dz1, const float* __restrict__ w1, float* __restrict__ dxr,
-                                                        int B) {
-    __shared__ float dz[32][64];
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    float acc[32];
+// dxr[b][k] = sum_j dz1[b][j] * w1[j][k]: the 134 MB weight matrix once more, now with k - the contiguous axis - as the MFMA's N index.
+// One workgroup = 128 k (256 of them); wave v contracts j = 256 v .. 256 v + 255, two j per step on v_mfma_f32_32x32x2_f32: lane (r, hh)
+// supplies A = dz1[sample r][j + hh] (from the transposed copy in LDS, pitch 33: no bank conflicts either way) and B = 16 bytes of row
+// j + hh, k = k0 + 4 r .. + 3, i.e. four MFMAs per load and every load instruction two runs of 512 contiguous bytes; eight loads in flight
+// per wave.  The four waves' sums meet in LDS (fixed order), a lane stores 16 bytes of one sample's row.  B <= 32 per launch.
+// (Round 2's form - one k per lane, 32 broadcast LDS reads and 32 FMAs per weight - took 344 us; this one ~50.)
+constexpr int FCX_PITCH = 33, FCX_LDS_BYTES = 1024 * FCX_PITCH * 4, FCX_DEPTH = 8;
+__global__ __launch_bounds__(256) void fc1_bwd_x_kernel(const float* __restrict__ dz1, const float* __restrict__ w1, float* __restrict__ dxr,
+                                                         int B) {
+    extern __shared__ __attribute__((aligned(16))) float fcx_smem[];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wv = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * 128;
+    for (int idx = threadIdx.x; idx < 32 * 1024; idx += 256) {
+        const int b = idx >> 10, jj = idx & 1023;
+        fcx_smem[jj * FCX_PITCH + b] = b < B ? dz1[(size_t)b * 1024 + jj] : 0.f;
+    }
+    __syncthreads();
+    const float* wp = w1 + (size_t)(256 * wv + hh) * FCK + k0 + 4 * r;
+    const float* ap = fcx_smem + (256 * wv + hh) * FCX_PITCH + r;
+    f32x16 acc[4];
 #pragma unroll
-    for (int b = 0; b < 32; ++b) acc[b] = 0.f;
-    for (int j0 = 0; j0 < 1024; j0 += 64) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 32 * 64; i += 64) {
-            const int b = i >> 6, jj = i & 63;
-            dz[b][jj] = b < B ? dz1[(size_t)b * 1024 + j0 + jj] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int jj = 0; jj < 64; ++jj) {
-            const float wv = w1[(size_t)(j0 + jj) * FCK + k];
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int b = 0; b < 32; ++b) acc[b] += dz[b][jj] * wv;
+        for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
+    f32x4 wq[FCX_DEPTH];
+#pragma unroll
+    for (int d = 0; d < FCX_DEPTH; ++d) wq[d] = __builtin_nontemporal_load((const f32x4*)(wp + (size_t)(2 * d) * FCK));
+    for (int st = 0; st < 128; st += FCX_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < FCX_DEPTH; ++d) {
+            const float a = ap[(2 * (st + d)) * FCX_PITCH];
+            const f32x4 wcur = wq[d];
+            if (st + FCX_DEPTH + d < 128) wq[d] = __builtin_nontemporal_load((const f32x4*)(wp + (size_t)(2 * (st + FCX_DEPTH + d)) * FCK));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wcur[e], acc[e], 0, 0, 0);
         }
     }
-    for (int b = 0; b < B; ++b) dxr[(size_t)b * FCK + k] = acc[b];
+    // element 4 g + e' of lane (r, hh) of acc[e] = sample 8 g + 4 hh + e', k = k0 + 4 r + e.  Waves 1-3 hand theirs over through LDS
+    // (the transposed dz1 is no longer needed): slot [wave - 1][element][e][lane]
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fcx_smem[(((wv - 1) * 16 + i) * 4 + e) * 64 + lane] = acc[e][i];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int b = 8 * (i >> 2) + 4 * hh + (i & 3);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = ((acc[e][i] + fcx_smem[((0 * 16 + i) * 4 + e) * 64 + lane]) + fcx_smem[((1 * 16 + i) * 4 + e) * 64 + lane]) +
+                       fcx_smem[((2 * 16 + i) * 4 + e) * 64 + lane];
+            if (b < B) *(f32x4*)(dxr + (size_t)b * FCK + k0 + 4 * r) = o;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
@@ -383,8 +418,9 @@ int hrn_shiftnet_backward(const hrn_shiftnet_params* P, const float* x, int B, c
     for (int b0 = 0; b0 < B; b0 += 32)
         hipLaunchKernelGGL(fc1_bwd_w_kernel, dim3(FCK / 256, 1024 / FC1_BWD_JT), dim3(256), 0, s, (const float*)dz1 + (size_t)b0 * 1024,
                            (const float*)xr + (size_t)b0 * FCK, mut(G->fc1_w), B - b0 < 32 ? B - b0 : 32);
-    for (int b0 = 0; b0 < B; b0 += 32)      // the kernel keeps 32 samples' partial sums in registers: larger batches go in groups
-        hipLaunchKernelGGL(fc1_bwd_x_kernel, dim3(FCK / 64), dim3(64), 0, s, (const float*)dz1 + (size_t)b0 * 1024, P->fc1_w,
+    { const int rc_lds = hrn_allow_lds((const void*)fc1_bwd_x_kernel, FCX_LDS_BYTES); if (rc_lds) return rc_lds; }
+    for (int b0 = 0; b0 < B; b0 += 32)      // 32 samples are the MFMA's M: larger batches go in groups
+        hipLaunchKernelGGL(fc1_bwd_x_kernel, dim3(FCK / 128), dim3(256), FCX_LDS_BYTES, s, (const float*)dz1 + (size_t)b0 * 1024, P->fc1_w,
                            dxr + (size_t)b0 * FCK, B - b0 < 32 ? B - b0 : 32);
     hipLaunchKernelGGL(fc_from_ref_kernel, dim3(ew_grid(nflat)), dim3(256), 0, s, (const float*)dxr, dropout_mask, cur, nflat);
     HRN_LAUNCH_CHECK();
