@@ -1,7 +1,7 @@
 // conv3x3 64 -> 64, bf16, RESIDENT weights + two ping-pong wave teams: the encoder's five 64->64 layers
 // (HRNet.py:17-22, :55-60).
 //
-// Why a third kernel: 64->64 sits at the MFMA/HBM ridge (288 FLOP/B), and in round 1's general bf16 kernel (conv3x3_v3, since deleted) its time was neither: every
+// Why a third kernel: 64->64 sits at the MFMA/HBM ridge (288 FLOP/B), and in conv3x3_v3 its time was neither: every
 // 256-pixel tile re-staged all 72 KB of weights through the slow ds_write path (a barrier per 3 taps), and the epilogue
 // (bias, PReLU, residual, rounding: ~2,000 VALU cycles per tile) ran while the matrix pipe idled.  For CIN = COUT = 64
 // the whole weight tensor fits in LDS for the lifetime of a persistent workgroup, next to TWO halo tiles:
