@@ -232,6 +232,31 @@ def test_hrnet_backward_with_nonpositive_slopes(slopes):
     assert util.rel_err(got, want_sr) <= 4e-2
 
 
+def test_bf16x3_backward_with_nonpositive_slopes():
+    """The same recomputation (ConvParams::only_if_nonpos) on the bf16x3 kernels: every PReLU at a non-positive slope.  Forward to the
+    bf16x3 bound; gradients against fp64 autograd in the L2 norm of each tensor - element-wise they carry the sign flips of
+    pre-activations within ~1e-5 of zero (test_bf16x3_gradients_with_default_slopes), each worth (1 - slope) of a term."""
+    B, V, S = 2, 5, 16
+    lrs, alphas, _ = synth.make_batch(5, B, V, S, 4)
+    rng = np.random.Generator(np.random.PCG64(78))
+    cot = rng.standard_normal((B, 1, 3 * S, 3 * S)).astype(np.float32)
+    want_sr, want = _oracle_grads(lrs, alphas, cot, True, slopes=NONPOS)
+    m = _fresh_model(True, slopes=NONPOS, precision="bf16x3")
+    sr = m(util.dev(lrs), util.dev(alphas))
+    assert util.rel_err(sr.detach().cpu().numpy(), want_sr) <= 1e-4
+    (sr * util.dev(cot)).sum().backward()
+    worst = {}
+    for k, p in m.named_parameters():
+        if p.numel() == 1:
+            continue
+        got = p.grad.cpu().numpy().astype(np.float64)
+        ref = np.asarray(want[k], np.float64)
+        worst[k] = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("bf16x3, non-positive slopes: worst relative L2 gradient errors", top)
+    assert top[0][1] <= 2e-2, top
+
+
 # ----------------------------------------------------------------------------- Lanczos shift backward
 _torch_lanczos_shift = torch_port.lanczos_shift      # fp64 torch restatement of lanczos.py:5-107, pinned by tests/golden/train_step.npz
 
