@@ -527,16 +527,20 @@ def measure_rank0(args, ws, device, net, lrs, alphas, step, sr_holder, binding, 
         extra(extras, "c2_fp32", c2)
 
         def lanczos_roof():
-            img = torch.rand((1, args.batch, 3 * args.size, 3 * args.size), device=device)
-            sh = (torch.rand((args.batch, 2), device=device) - 0.5) * 2
-            f = lambda: binding.lanczos_shift(img, sh)         # noqa: E731
-            timed_local(f, 3, 2, device)
-            pf = profile_families(binding, device, f, 10)["lanczos_shift"]
-            gbs = pf["bytes"] / pf["ms"] / 1e6
-            return {"kernel": "lanczos_shift", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(pf["ms"] / pf["launches"], 4),
-                    "algorithmic_bytes_per_launch": pf["bytes"] / pf["launches"],
-                    "workload": f"lanczos_shift of {args.batch} images of {3 * args.size}x{3 * args.size} (one launch; SURVEY 8d: 2*B*9HW*4 B)"}
+            def at(side):
+                img = torch.rand((1, args.batch, side, side), device=device)
+                sh = (torch.rand((args.batch, 2), device=device) - 0.5) * 2
+                f = lambda: binding.lanczos_shift(img, sh)         # noqa: E731
+                timed_local(f, 3, 2, device)
+                pf = profile_families(binding, device, f, 10)["lanczos_shift"]
+                gbs = pf["bytes"] / pf["ms"] / 1e6
+                return {"achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(pf["ms"] / pf["launches"], 4),
+                        "algorithmic_bytes_per_launch": pf["bytes"] / pf["launches"],
+                        "workload": f"lanczos_shift of {args.batch} images of {side}x{side} (one launch; SURVEY 8d: 2*B*9HW*4 B)"}
+            r = {"kernel": "lanczos_shift", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+            r.update(at(3 * args.size))
+            r["at_config5_size"] = at(3 * 512)                     # BASELINE configs[4]: 1536 x 1536 (the metric's 384 x 384 is 38 MB: a launch)
+            return r
         extra(extras, "roofline_lanczos", lanczos_roof)
 
         def shiftnet_fwd():

@@ -37,8 +37,9 @@ __global__ void lanczos_taps_kernel(const float* __restrict__ d, float* __restri
     for (int j = 0; j < 7; ++j) taps[i * 7 + j] = k[j];
 }
 
-constexpr int LT_H = 16, LT_W = 64;      // output tile; 256 threads
-constexpr int LH = LT_H + 6, LW = LT_W + 6;
+constexpr int LT_H = 32, LT_W = 128;     // output tile; 256 threads.  (Round 1's 16 x 64 tile read 1.5 x its output and reached 1.5 TB/s at
+constexpr int LH = LT_H + 6, LW = LT_W + 6;      // 1536 x 1536; this one reads 1.24 x, row by row per wave)
+constexpr int LRG = 4;                   // rows per task of the vertical pass
 
 __device__ __forceinline__ int reflect(int g, int n) {
     g = g < 0 ? -g : g;
@@ -48,8 +49,8 @@ __device__ __forceinline__ int reflect(int g, int n) {
 // img/out [b][c][H][W] f32; shift [c][2] = (dy, dx).  grid = (tiles_x * tiles_y, b * c)
 __global__ __launch_bounds__(256) void lanczos_shift_kernel(const float* __restrict__ img, const float* __restrict__ shift,
                                                             float* __restrict__ out, int C, int H, int W) {
-    __shared__ float tile[LH][LW + 1];
-    __shared__ float tmp[LT_H][LW + 1];
+    __shared__ float tile[LH][LW + 2];
+    __shared__ float tmp[LT_H][LW + 2];
     __shared__ float kyx[2][7];
     const int plane = blockIdx.y;             // b*C + c
     const int ch = plane % C;
@@ -57,36 +58,71 @@ __global__ __launch_bounds__(256) void lanczos_shift_kernel(const float* __restr
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * LT_H, x0 = tx * LT_W;
     const float* src = img + (size_t)plane * H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 2) {
         float k[7];
         taps7(shift[ch * 2 + threadIdx.x], k);
 #pragma unroll
         for (int j = 0; j < 7; ++j) kyx[threadIdx.x][j] = k[j];
     }
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
-        const int yy = i / LW, xx = i - yy * LW;
-        const int gy = reflect(y0 + yy - 3, H), gx = reflect(x0 + xx - 3, W);
-        // tiles hanging over the image edge read clamped (unused) pixels
-        const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-        tile[yy][xx] = src[(size_t)cy * W + cx];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < LT_H * LW; i += 256) {      // vertical pass (lanczos.py:90)
-        const int yy = i / LW, xx = i - yy * LW;
-        float s = 0.f;
+    // halo tile, a row per wave at a time: consecutive lanes read consecutive pixels.  Reflected at the image border; tiles hanging over
+    // the edge read clamped (unused) pixels
+    // (all of a wave's ~30 loads are issued before the first is stored: 7.5 KB per wave in flight.  With a load - store pair per
+    // iteration a CU had ~6 KB on the wire and the kernel sat at 1.5 TB/s whatever its tile)
+    {
+        constexpr int NR = (LH + 3) / 4, NC = (LW + 63) / 64;
+        float v[NR][NC];
+        int cxs[NC];
 #pragma unroll
-        for (int m = 0; m < 7; ++m) s += kyx[0][m] * tile[yy + m][xx];
-        tmp[yy][xx] = s;
+        for (int k = 0; k < NC; ++k) {
+            const int gx = reflect(x0 + lane + 64 * k - 3, W);
+            cxs[k] = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int yy = wave + 4 * i;
+            const int gy = reflect(y0 + (yy < LH ? yy : LH - 1) - 3, H);
+            const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+            const float* row = src + (size_t)cy * W;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) v[i][k] = (lane + 64 * k < LW) ? row[cxs[k]] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int yy = wave + 4 * i;
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                if (yy < LH && lane + 64 * k < LW) tile[yy][lane + 64 * k] = v[i][k];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < LT_H * LT_W; i += 256) {    // horizontal pass (lanczos.py:94)
-        const int yy = i / LT_W, xx = i - yy * LT_W;
-        const int gy = y0 + yy, gx = x0 + xx;
-        if (gy < H && gx < W) {
+    // vertical pass (lanczos.py:90): a task = LRG output rows of one column from a sliding window of LRG + 6 values
+    float ky[7], kx[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) { ky[m] = kyx[0][m]; kx[m] = kyx[1][m]; }
+    for (int t = threadIdx.x; t < (LT_H / LRG) * LW; t += 256) {
+        const int g = t / LW, xx = t - g * LW;
+        float v[LRG + 6];
+#pragma unroll
+        for (int i = 0; i < LRG + 6; ++i) v[i] = tile[LRG * g + i][xx];
+#pragma unroll
+        for (int i = 0; i < LRG; ++i) {
             float s = 0.f;
 #pragma unroll
-            for (int m = 0; m < 7; ++m) s += kyx[1][m] * tmp[yy][xx + m];
-            out[(size_t)plane * H * W + (size_t)gy * W + gx] = s;
+            for (int m = 0; m < 7; ++m) s += ky[m] * v[i + m];
+            tmp[LRG * g + i][xx] = s;
+        }
+    }
+    __syncthreads();
+    // horizontal pass (lanczos.py:94): thread = one column, every second row; a wave writes 256 contiguous bytes
+    {
+        const int xx = threadIdx.x & (LT_W - 1), gx = x0 + xx;
+        for (int yy = threadIdx.x / LT_W; yy < LT_H; yy += 256 / LT_W) {
+            const int gy = y0 + yy;
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) s += kx[m] * tmp[yy][xx + m];
+            if (gy < H && gx < W) out[(size_t)plane * H * W + (size_t)gy * W + gx] = s;
         }
     }
 }
