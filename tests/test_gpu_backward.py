@@ -191,6 +191,31 @@ def test_hrnet_train_step_reduces_loss():
     assert float(after) < losses[0]
 
 
+def test_bf16x3_training_tracks_fp32_training():
+    """Twenty Adam steps from the same initial weights on the same batch, HRNet once on the fp32 and once on the bf16x3 training
+    kernels: the two loss curves stay together (the modes differ by ~2e-5 per forward; Adam's sign-like first steps amplify that, so
+    the bound is on the curve, not on bits) and both fall."""
+    lrs, alphas, _ = synth.make_batch(9, 2, 4, 16, 4)
+    x, a = util.dev(lrs), util.dev(alphas)
+    target = torch.zeros((2, 1, 48, 48), device="cuda") + 0.1
+    curves = {}
+    for prec in ("fp32", "bf16x3"):
+        m = _fresh_model(precision=prec)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        curve = []
+        for _ in range(20):
+            opt.zero_grad()
+            loss = ((m(x, a) - target) ** 2).mean()
+            loss.backward()
+            opt.step()
+            curve.append(float(loss.detach()))
+        curves[prec] = np.array(curve)
+    rel = np.abs(curves["bf16x3"] - curves["fp32"]) / curves["fp32"]
+    print("fp32 vs bf16x3 training: loss", curves["fp32"][[0, 9, 19]], curves["bf16x3"][[0, 9, 19]], "max rel diff", rel.max())
+    assert curves["fp32"][-1] < 0.5 * curves["fp32"][0] and curves["bf16x3"][-1] < 0.5 * curves["bf16x3"][0]
+    assert rel.max() <= 2e-2, rel
+
+
 NONPOS = {"encode.init_layer.1.weight": -0.2, "encode.res_layers.0.block.1.weight": 0.0, "encode.res_layers.0.block.3.weight": -0.05,
           "encode.res_layers.1.block.3.weight": -0.3, "fuse.fuse.0.block.1.weight": -0.1, "fuse.fuse.0.block.3.weight": 0.0,
           "fuse.fuse.2.weight": -0.25, "decode.deconv.1.weight": -0.1}
