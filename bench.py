@@ -543,6 +543,62 @@ def measure_rank0(args, ws, device, net, lrs, alphas, step, sr_holder, binding, 
             return r
         extra(extras, "roofline_lanczos", lanczos_roof)
 
+        def host_buffers():
+            """The boundary with HOST buffers (never `value`): lrs / alphas in pinned host memory in, the SR frames in pinned host memory
+            out - serially on one stream, and double-buffered with the copies on their own HIP streams beside the kernels."""
+            n_it = 10
+            h_lrs, h_al = lrs.cpu().pin_memory(), alphas.cpu().pin_memory()
+            h_sr = torch.empty((args.batch, 1, 3 * args.size, 3 * args.size)).pin_memory()
+
+            def serial():
+                d_l, d_a = h_lrs.to(device, non_blocking=True), h_al.to(device, non_blocking=True)
+                h_sr.copy_(net(d_l, d_a), non_blocking=True)
+            t_serial = timed_local(serial, n_it, 2, device) / n_it
+            s_in, s_out, s_main = torch.cuda.Stream(device), torch.cuda.Stream(device), torch.cuda.current_stream(device)
+            d_in = [(torch.empty_like(lrs), torch.empty_like(alphas)) for _ in range(2)]
+            d_out = [torch.empty_like(h_sr, device=device) for _ in range(2)]
+            h_out = [torch.empty_like(h_sr).pin_memory() for _ in range(2)]
+            ev_in = [torch.cuda.Event() for _ in range(2)]
+            ev_done = [torch.cuda.Event() for _ in range(2)]
+            ev_free = [torch.cuda.Event() for _ in range(2)]
+
+            def upload(i):
+                b = i & 1
+                with torch.cuda.stream(s_in):
+                    s_in.wait_event(ev_free[b])                     # the forward that read this input pair has run
+                    d_in[b][0].copy_(h_lrs, non_blocking=True)
+                    d_in[b][1].copy_(h_al, non_blocking=True)
+                    ev_in[b].record(s_in)
+
+            def pipelined(n):
+                for b in range(2):
+                    ev_free[b].record(s_main)
+                upload(0)
+                for i in range(n):
+                    b = i & 1
+                    if i + 1 < n:
+                        upload(i + 1)
+                    s_main.wait_event(ev_in[b])
+                    s_main.wait_event(ev_done[b])                   # the download that read d_out[b] two steps ago has run
+                    d_out[b].copy_(net(d_in[b][0], d_in[b][1]))
+                    ev_free[b].record(s_main)
+                    with torch.cuda.stream(s_out):
+                        s_out.wait_stream(s_main)
+                        h_out[b].copy_(d_out[b], non_blocking=True)
+                        ev_done[b].record(s_out)
+                torch.cuda.synchronize(device)
+            for b in range(2):
+                ev_done[b].record(s_out)
+            pipelined(3)
+            t0 = time.perf_counter()
+            pipelined(n_it)
+            t_pipe = (time.perf_counter() - t0) / n_it
+            return {"serial_frames_per_s": round(args.batch / t_serial, 1), "serial_ms_per_step": round(t_serial * 1e3, 3),
+                    "overlapped_frames_per_s": round(args.batch / t_pipe, 1), "overlapped_ms_per_step": round(t_pipe * 1e3, 3),
+                    "bytes_in": lrs.numel() * 4 + alphas.numel() * 4, "bytes_out": h_sr.numel() * 4,
+                    "note": "pinned host buffers; overlapped = H2D, kernels and D2H on three HIP streams, inputs and outputs double-buffered"}
+        extra(extras, "host_buffers", host_buffers)
+
         def shiftnet_fwd():
             from DeepNetworks.ShiftNet import ShiftNet
             sn = ShiftNet().to(device).eval()
