@@ -466,9 +466,15 @@ def measure_rank0(args, ws, device, net, lrs, alphas, step, sr_holder, binding, 
     enc = [prof[f] for f in prof if f.startswith("conv3x3_") and "_64x64" in f]
     if enc:
         ems, efl = sum(f["ms"] for f in enc), sum(f["flops"] for f in enc)
+        eby = sum(f["bytes"] for f in enc)
+        ectr = sum(tj["bytes_per_launch"].get(k, 0) * kernels[k]["launches_per_step"] for k in kernels if "_64x64" in k) if tj else None
         line["roofline_encoder"] = {"stage": "encoder 64->64 convs (north_star: >= 0.70 of the MFMA roof)", "bound": "mfma", "unit": "TFLOP/s",
                                     "achieved": round(efl / ems / 1e9, 1), "peak": peak, "frac": round(efl / ems / 1e9 / peak, 4),
-                                    "ms": round(ems / nprof, 3)}
+                                    "ms": round(ems / nprof, 3),
+                                    # 288 FLOP/B: the stage sits at the ridge, and on this part it is the memory side it runs into first
+                                    "hbm": {"achieved": round(eby / ems / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                            "frac": round(eby / ems / 1e6 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eby / nprof,
+                                            "traffic": ectr, "traffic_gbs": round(ectr / (ems / nprof) / 1e6, 1) if ectr else None}}
 
     # ---- parity of the run that was timed: against the exact-fp32 HIP path on the same batch (cPSNR: Evaluator.py:34-38, all-ones mask)
     parity, extras = line["parity"], {}
