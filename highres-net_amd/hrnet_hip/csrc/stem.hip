@@ -163,15 +163,20 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     constexpr int SROW = 144;                                        // staged pixel row: 64 bf16 + 16 B pad
     constexpr int NK = X3 ? 4 : 3;                                   // k-steps of 16
     __shared__ __attribute__((aligned(16))) unsigned char stg_all[(X3 ? 2 : 1) * 4 * 32 * SROW];
-    __shared__ __attribute__((aligned(16))) float bl[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (uniform: the segment arithmetic below stays on the scalar unit)
     const int r = lane & 31, hh = lane >> 5;
-    if (tid < 64) bl[tid] = bias[tid];
-    __syncthreads();
     const float a = slope ? slope[0] : 1.f;
     unsigned char* stg = stg_all + wave * 32 * SROW;
 
-    // A operand: lane (r, hh) holds W2[co = cb*32 + r][k = 16 s + 8 hh + j], W2[co][k] = w[co][k mod 18] for k < 36, else 0
+    // K layout (round 3): the two 32-lane halves of the wave take one INPUT CHANNEL each (hh = 0: the view, hh = 1: the reference frame),
+    // so a lane loads and splits only its own 9 taps, and nothing is selected by hh afterwards.  Slot n = 8 s + j of lane (r, hh):
+    //   B (pixel r):  n 0..8 hi[n] | 9..17 lo[n - 9] | 18 the constant 1 | X3: 19..27 hi[n - 19] | else 0
+    //   A (cout r):   n 0..8 Wh[hh][n] | 9..17 Wh[hh][n - 9] | 18 bias: its bf16 hi part in the hh = 0 half, its lo part in the other |
+    //                 X3: 19..27 Wl[hh][n - 19] | else 0          (Wh = bf16(w), Wl = bf16(w - Wh))
+    // i.e. W hi x X (hi + lo) (+ W lo x X hi) + bias in one accumulation: fp32-grade products, no bias add in the epilogue.
+    // (Until round 3 every lane converted all 18 taps and picked 12 of the 24 by hh: ~330 VALU per 32 pixels, and the kernel sat at
+    // 3.7 TB/s of writes where a fill reaches 6.7.)
     bf16x8 wa[2][NK];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -179,44 +184,59 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         for (int s = 0; s < NK; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * hh + j;
-                const float v = k < (X3 ? 54 : 36) ? w[(cb * 32 + r) * 18 + (k % 18)] : 0.f;
+                const int n = 8 * s + j, co = cb * 32 + r;
+                float v = 0.f;
+                bool want_lo = false;
+                if (n < 18) v = w[co * 18 + hh * 9 + (n % 9)];
+                else if (n == 18) { v = bias[co]; want_lo = hh != 0; }
+                else if (X3 && n < 28) { v = w[co * 18 + hh * 9 + (n - 19)]; want_lo = true; }
                 const __bf16 h = (__bf16)v;
-                wa[cb][s][j] = (X3 && k >= 36) ? (__bf16)(v - (float)h) : h;      // third block: the weights' lo halves
+                wa[cb][s][j] = want_lo ? (__bf16)(v - (float)h) : h;
             }
+    const float act_pick = a <= 1.f ? __builtin_inff() : -__builtin_inff();      // PReLU(t) = median(t, a t, +-inf)
 
+    // segments (image m, row y, 32-pixel run sx), walked with a stride of gridDim.x * 4: the position is advanced by the stride's own
+    // (dm, dy, dsx) with carries - no division per segment (the launcher keeps M * H * segs_x below 2^31)
     const int segs_x = (W + 31) >> 5;
-    const size_t nseg = (size_t)M * H * segs_x;
-    for (size_t si = (size_t)blockIdx.x * 4 + wave; si < nseg; si += (size_t)gridDim.x * 4) {
-        const int sx = (int)(si % segs_x);
-        const int y = (int)((si / segs_x) % H);
-        const int m = (int)(si / ((size_t)segs_x * H));
+    const unsigned nseg = (unsigned)M * (unsigned)H * (unsigned)segs_x;
+    const unsigned seg_step = gridDim.x * 4u;
+    const int d_sx = (int)(seg_step % (unsigned)segs_x), d_y = (int)((seg_step / (unsigned)segs_x) % (unsigned)H);
+    const int d_m = (int)(seg_step / ((unsigned)segs_x * (unsigned)H));
+    auto advance = [&](int& m, int& y, int& sx) __attribute__((always_inline)) {
+        sx += d_sx; y += d_y; m += d_m;
+        if (sx >= segs_x) { sx -= segs_x; ++y; }
+        if (y >= H) { y -= H; ++m; }
+    };
+    // the 9 taps of this lane's channel at a segment (zeros outside the image); loaded one segment ahead
+    auto load_taps = [&](int m, int y, int sx, float (&v)[9]) __attribute__((always_inline)) {
         const int x = sx * 32 + r;
-        const float* p0 = in0 + (size_t)m * img_stride0;
-        const float* p1 = in1 + (size_t)(m / rep1) * img_stride1;
-        // this pixel's 3x3x2 window, split into hi / lo bf16.  Row tests and row bases are scalar (y is the wave's), the column tests
-        // three per segment: a load costs one add
-        __bf16 hi[18], lo[18];
-        bool okx[3];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) okx[dx] = (unsigned)(x + dx - 1) < (unsigned)W;
+        const float* pb = hh ? in1 + (size_t)(m / rep1) * img_stride1 : in0 + (size_t)m * img_stride0;
+        // (predicated loads from one row base with constant offsets; clamped addresses + a select per tap were measured slower: 0.62
+        // against 0.44 ms - every tap then needs its own 64-bit address)
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int gy = y + dy - 1;                          // uniform
             const bool oky = (unsigned)gy < (unsigned)H;
-            const size_t ro = (size_t)(oky ? gy : 0) * W + (x - 1);
+            const float* rp = pb + (size_t)(oky ? gy : 0) * W + (x - 1);
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-                const float* rp = (ci == 0 ? p0 : p1) + ro;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = (oky && okx[dx]) ? rp[dx] : 0.f;
-                    const __bf16 h = (__bf16)v;
-                    hi[ci * 9 + dy * 3 + dx] = h;
-                    lo[ci * 9 + dy * 3 + dx] = (__bf16)(v - (float)h);
-                }
-            }
+            for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = (oky && (unsigned)(x + dx - 1) < (unsigned)W) ? rp[dx] : 0.f;
         }
+    };
+    unsigned si = blockIdx.x * 4u + (unsigned)wave;
+    int sx = (int)(si % (unsigned)segs_x), y = (int)((si / (unsigned)segs_x) % (unsigned)H), m = (int)(si / ((unsigned)segs_x * (unsigned)H));
+    int nsx = sx, ny = y, nm = m;
+    float vn[9];
+    if (si < nseg) load_taps(m, y, sx, vn);
+    for (; si < nseg; si += seg_step, sx = nsx, y = ny, m = nm) {
+        __bf16 hi[9], lo[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const __bf16 h = (__bf16)vn[t];
+            hi[t] = h;
+            lo[t] = (__bf16)(vn[t] - (float)h);
+        }
+        advance(nm, ny, nsx);
+        if (si + seg_step < nseg) load_taps(nm, ny, nsx, vn);
         f32x16 acc[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -227,13 +247,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             bf16x8 bq;                                               // B[k = 16 s + 8 hh + j][col = this pixel]
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k0 = 16 * s + j, k1 = k0 + 8;              // the two candidates: hh = 0 / hh = 1
-                const __bf16 z = (__bf16)0.f;
-                auto pick = [&](int k) __attribute__((always_inline)) -> __bf16 {
-                    return k < 18 ? hi[k] : (k < 36 ? lo[k - 18] : ((X3 && k < 54) ? hi[k - 36] : z));
-                };
-                const __bf16 c0 = pick(k0), c1 = pick(k1);
-                bq[j] = hh ? c1 : c0;
+                const int n = 8 * s + j;
+                bq[j] = n < 9 ? hi[n] : (n < 18 ? lo[n - 9] : (n == 18 ? (__bf16)1.f : ((X3 && n < 28) ? hi[n - 19] : (__bf16)0.f)));
             }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], bq, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s], bq, acc[1], 0, 0, 0);
@@ -247,8 +262,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float t = acc[cb][4 * g + j] + bl[co + j];
-                    v[j] = t >= 0.f ? t : a * t;
+                    const float t = acc[cb][4 * g + j];              // (the bias came in through the K axis)
+                    v[j] = __builtin_amdgcn_fmed3f(t, a * t, act_pick);
                 }
                 if constexpr (X3) {
                     uint2 uh, ul;
@@ -339,6 +354,8 @@ int hrn_launch_stem(int dt, const float* in0, size_t img_stride0, const float* i
     const int blocks = (int)(patches < 16384 ? patches : 16384);
     const double px = (double)M * H * W;
     HrnProfScope prof(dt == HRN_BF16 ? "stem2x64_bf16" : dt == HRN_BF16X3 ? "stem2x64_bf16x3" : "stem2x64_f32", 2.0 * 18 * 64 * px, px * (4 + (double)M / rep1 / M * 4 + 64.0 * hrn_esize(dt)), stream);
+    if ((dt == HRN_BF16 || dt == HRN_BF16X3) && sub == nullptr)
+        HRN_CHECK((size_t)M * H * ((W + 31) / 32) < ((size_t)1 << 31), -2, "stem: %d images of %d x %d exceed the 32-bit segment count", M, H, W);
     if (dt == HRN_BF16 && sub == nullptr) {
         const size_t nseg = (size_t)M * H * ((W + 31) / 32);
         const int mblocks = (int)((nseg + 3) / 4 < 8192 ? (nseg + 3) / 4 : 8192);
